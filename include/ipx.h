@@ -1,0 +1,233 @@
+/* ipx.h -- C ABI of the MI355X junction-extraction library (libipx.so).
+ *
+ * This is the drop-in boundary for the one hot path of diekhans/intronProspector
+ * v1.4.0 that runs on the GPU: alignments (already decoded into SoA batches) ->
+ * junction records -> per-junction aggregate table.  The reference has no FFI;
+ * its de-facto interface for this path is the C++ class JunctionsExtractor
+ * (src/junctions_extractor.hh:73-256).  Each entry point below names the
+ * reference member it stands for (paths relative to /root/reference).
+ *
+ * Conventions: plain C types only; every function returns 0 (IPX_OK) or an
+ * IPX_E* code and never throws; one handle is used from one thread at a time;
+ * different handles are independent.  The library has no CPU fallback: if no
+ * gfx950 device can be opened ipx_create fails with IPX_ENODEVICE.
+ */
+#ifndef IPX_H
+#define IPX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPX_ABI_VERSION 1
+
+/* status codes */
+enum {
+    IPX_OK = 0,
+    IPX_EINVAL = 1,        /* bad argument / unsupported configuration           */
+    IPX_ENODEVICE = 2,     /* no usable HIP device (no CPU fallback exists)       */
+    IPX_ENOMEM = 3,        /* device or pinned-host allocation failed             */
+    IPX_EDEVICE = 4,       /* HIP runtime error; see ipx_last_error().detail      */
+    IPX_EDATA = 5          /* the input raised one of the reference's exceptions;
+                              see ipx_last_error() for which and where            */
+};
+
+/* data errors, ipx_error.kind: the reference exception each one stands for */
+enum {
+    IPX_DATA_NONE = 0,
+    IPX_DATA_CIGAR = 1,        /* invalid_argument "Unknown cigar operation 'P'"
+                                  junctions_extractor.cc:312-313; op char in .op  */
+    IPX_DATA_CATEGORY = 2,     /* logic_error "should never look at FQCAIL, FUNMAP,
+                                  FDUP reads"  junctions_extractor.cc:73-74        */
+    IPX_DATA_GENOME_MISSING = 3, /* runtime_error "can't load genome sequence for:"
+                                  genome.cc:65-67; coordinates in .start/.end      */
+    IPX_DATA_GENOME_SHORT = 4, /* runtime_error "unexpected length returned for:"
+                                  genome.cc:68-70; returned length in .retlen      */
+    IPX_DATA_TARGET = 5        /* tid >= number of targets (undefined behaviour in
+                                  the reference, junctions_extractor.cc:538)       */
+};
+
+/* splice_juncs.hh:12-16 */
+enum { IPX_SJ_NULL = 0, IPX_SJ_ALL = 1, IPX_SJ_CANON = 2 };
+/* junctions_extractor.hh:56-60 */
+enum { IPX_UNSTRANDED = 0, IPX_RF_STRANDED = 1, IPX_FR_STRANDED = 2 };
+/* junctions_extractor.hh:64-67 */
+enum { IPX_EXCLUDE_NONE = 0, IPX_EXCLUDE_MULTI = 1 };
+/* table scope: which JunctionTable lifetime the caller reproduces */
+enum {
+    IPX_SCOPE_TARGET = 0,  /* one table per target, intronProspector.cc:364-368:
+                              key = (tid, start, end)                              */
+    IPX_SCOPE_GLOBAL = 1   /* one table for the run (--unsorted / several inputs),
+                              intronProspector.cc:375-401: key = (chrom NAME,
+                              start, end), names ordered as std::string            */
+};
+
+/* by-value parameters of the JunctionsExtractor constructor,
+ * junctions_extractor.hh:176-207 (pass-through/tag/trace members excluded) */
+typedef struct ipx_params {
+    uint32_t min_anchor_length;       /* default 8       intronProspector.cc:44 */
+    uint32_t max_anchor_indel_size;   /* 0 unless --allow-anchor-indels :289-292 */
+    uint32_t min_intron_length;       /* default 70      :45 */
+    uint32_t max_intron_length;       /* default 500000  :46 */
+    int32_t  sj_filter;               /* IPX_SJ_*  */
+    int32_t  strandness;              /* IPX_UNSTRANDED / RF / FR */
+    uint32_t excludes;                /* IPX_EXCLUDE_* bits */
+    int32_t  scope;                   /* IPX_SCOPE_* */
+    int32_t  skip_missing_targets;    /* --skip-missing-targets */
+    int32_t  device;                  /* HIP device ordinal */
+} ipx_params;
+
+/* One batch of decoded alignments, structure of arrays, 20 bytes per alignment
+ * plus 4 bytes per CIGAR operation.  This is what the reference reads from a
+ * bam1_t in process_alignment (junctions_extractor.cc:49-56,71-95,184-205,
+ * 285-290,322-371,533-536):
+ *   tid        core.tid
+ *   pos        core.pos (0-based)
+ *   flag       core.flag
+ *   xs         0 if the record has no XS tag, else the byte
+ *              get_junction_strand_XS() returns ('.' when bam_aux2A yields 0)
+ *   nh         get_num_aligns() class: 0 = no NH tag or value <= 0,
+ *              1 = NH == 1, 2 = NH > 1
+ *   cigar_off  index of the record's first word in cigar[]
+ *   n_cigar    core.n_cigar
+ *   cigar      bam_get_cigar() words, BAM packing (len << 4 | op)
+ * The caller lists alignments in the order the reference's read loop would
+ * hand them to process_alignment; base_read_index is the position of
+ * alignment 0 in that order over the whole run.
+ */
+typedef struct ipx_batch {
+    uint64_t n_alignments;
+    uint64_t n_cigar_words;
+    uint64_t base_read_index;
+    const int32_t  *tid;
+    const int32_t  *pos;
+    const uint16_t *flag;
+    const uint8_t  *xs;
+    const uint8_t  *nh;
+    const uint32_t *cigar_off;
+    const uint32_t *n_cigar;
+    const uint32_t *cigar;
+    int32_t memory;            /* IPX_MEM_HOST or IPX_MEM_DEVICE */
+} ipx_batch;
+
+enum { IPX_MEM_HOST = 0, IPX_MEM_DEVICE = 1 };
+
+/* motif byte of a junction: what get_splice_sites() fetched
+ * (junctions_extractor.cc:405-428) */
+#define IPX_MOTIF_PRESENT 0x8000u  /* genome consulted and sequence present        */
+#define IPX_MOTIF_NONACGT 0x4000u  /* at least one of the four bases is not ACGT:
+                                      the caller must take the bytes from its
+                                      FASTA to print them                          */
+#define IPX_MOTIF_CANON_P 0x2000u  /* is_canonical(donor/acceptor as read)         */
+#define IPX_MOTIF_CANON_RC 0x1000u /* is_canonical(reverse complement)             */
+/* bits 7..0: 2-bit codes (A0 C1 G2 T3) of genome[start], [start+1], [end-2],
+ * [end-1], first base in bits 7..6 */
+
+/* The aggregate table, structure of arrays, rows in std::map<JunctionKey,...>
+ * order (junctions.hh:77-100).  Stands for JunctionTable / get_junctions()
+ * (junctions.hh:225-246, junctions_extractor.hh:253-255) with the fields the
+ * printers read (junctions.cc:189-225).  Memory is owned by the handle and
+ * stays valid until the next ipx_finalize / ipx_clear / ipx_destroy. */
+typedef struct ipx_table {
+    uint64_t n_junctions;
+    const uint32_t *target;        /* tid (IPX_SCOPE_TARGET) or the first tid that
+                                      carries the chromosome name (IPX_SCOPE_GLOBAL) */
+    const uint32_t *intron_start;
+    const uint32_t *intron_end;
+    const uint32_t *anchor_start;  /* min over counted records */
+    const uint32_t *anchor_end;    /* max over counted records */
+    const uint8_t  *strand;        /* Junction::strand after correct_strand() */
+    const uint16_t *motif;         /* IPX_MOTIF_* */
+    const uint64_t *read_counts;   /* 3 per junction: single, multi, unsure */
+    const uint64_t *creator_index; /* global read index of the creating record */
+    const uint32_t *ijunc;         /* rank of creation inside this table; the
+                                      caller adds the run's running ijunc_
+                                      (junctions_extractor.hh:129,202)             */
+    /* read_offsets multiset (junctions.hh:121) as a histogram, CSR:
+     * bins hist_begin[j] .. hist_begin[j+1]-1, values ascending */
+    const uint64_t *hist_begin;    /* n_junctions + 1 */
+    const uint16_t *hist_value;
+    const uint32_t *hist_count;
+    uint64_t n_hist;
+    /* statistics of the finalized batches */
+    uint64_t n_alignments;
+    uint64_t n_records;            /* junction records that passed junction_qc */
+    int32_t  memory;               /* IPX_MEM_HOST or IPX_MEM_DEVICE */
+} ipx_table;
+
+typedef struct ipx_error {
+    int32_t  status;      /* last non-zero status */
+    int32_t  kind;        /* IPX_DATA_* when status == IPX_EDATA */
+    uint64_t read_index;  /* global index of the alignment that raised it */
+    uint32_t target;      /* its tid */
+    uint32_t start, end;  /* genome errors: the [start,end) that was fetched */
+    int32_t  retlen;      /* IPX_DATA_GENOME_SHORT: bytes the fetch returned */
+    char     op;          /* IPX_DATA_CIGAR: the operation character */
+    char     detail[235]; /* human-readable text (HIP error string, ...) */
+} ipx_error;
+
+typedef struct ipx_handle ipx_handle;
+
+uint32_t ipx_abi_version(void);
+
+/* JunctionsExtractor::JunctionsExtractor, junctions_extractor.hh:176-207 */
+int ipx_create(const ipx_params *params, ipx_handle **out);
+/* JunctionsExtractor::~JunctionsExtractor, junctions_extractor.cc:375-380 */
+int ipx_destroy(ipx_handle *h);
+
+/* save_targets(), junctions_extractor.cc:564-568: REPLACES the handle's target
+ * list with names[0..n) (the caller keeps the reference's append-per-open
+ * concatenation and passes the whole vector).  lengths may be NULL; when given
+ * (header LN) they only tighten the sort-key width. */
+int ipx_set_targets(ipx_handle *h, uint32_t n, const char *const *names, const int64_t *lengths);
+
+/* Genome (genome.hh:15-25), device-resident: n_seqs sequences, each given as
+ * 2-bit codes (4 bases per byte, first base in the low bits) and a non-ACGT
+ * mask (8 bases per byte, first base in bit 0).  Sequence names are matched to
+ * target names the way Genome::has_seq/fetch are called with the chromosome
+ * name (junctions_extractor.cc:411,419-420).  n_seqs == 0 removes the genome. */
+int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names,
+                        const int64_t *lengths, const uint8_t *const *twobit,
+                        const uint8_t *const *mask);
+
+/* Optional: size device buffers once, before timing. */
+int ipx_reserve(ipx_handle *h, uint64_t n_alignments, uint64_t n_cigar_words, uint64_t n_records);
+
+/* process_alignment() over a batch (junctions_extractor.cc:533-549): scans the
+ * CIGAR streams on the device and appends the QC-passed junction records to
+ * the handle.  Batch memory is borrowed until the call returns. */
+int ipx_push_batch(ipx_handle *h, const ipx_batch *batch);
+
+/* Sort + reduce every record pushed since the last ipx_clear into the junction
+ * table.  memory selects where the returned arrays live.  If the input raised a
+ * reference exception the call returns IPX_EDATA and ipx_last_error() tells
+ * which alignment and why (the earliest one in input order); *out then
+ * describes the table of the records BEFORE that alignment. */
+int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out);
+
+/* JunctionsExtractor::clear(), junctions_extractor.hh:223-225: drops records and
+ * table; targets, genome and parameters stay. */
+int ipx_clear(ipx_handle *h);
+
+int ipx_last_error(const ipx_handle *h, ipx_error *out);
+
+/* --- multi-GPU support: partial tables over a contiguous shard
+ * of the run's alignments, to be combined with RCCL by the caller ------------ */
+
+/* Like ipx_finalize(IPX_MEM_DEVICE) but for one shard of a larger run: returns
+ * in addition, per junction, the tallies over ALL the shard's records of the key
+ * (what the junction receives if an earlier shard created it).  `out_all` rows
+ * correspond 1:1 to keys[]; a key none of whose records passes the filter has
+ * creator_index == UINT64_MAX in `out`. */
+int ipx_finalize_shard(ipx_handle *h, ipx_table *out_from_creator, ipx_table *out_all);
+
+/* device timing of the last ipx_push_batch / ipx_finalize in milliseconds,
+ * measured with HIP events on the handle's stream */
+int ipx_last_timing(const ipx_handle *h, float *push_ms, float *finalize_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""ctypes view of include/ipx.h (libipx.so, built in-tree by csrc/Makefile).
+
+There is no Python or CPU fallback: if the shared library is missing, or no
+gfx950 device can be opened, the caller gets an exception.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libipx.so")
+
+IPX_OK, IPX_EINVAL, IPX_ENODEVICE, IPX_ENOMEM, IPX_EDEVICE, IPX_EDATA = range(6)
+IPX_MEM_HOST, IPX_MEM_DEVICE = 0, 1
+IPX_SJ_NULL, IPX_SJ_ALL, IPX_SJ_CANON = 0, 1, 2
+IPX_UNSTRANDED, IPX_RF_STRANDED, IPX_FR_STRANDED = 0, 1, 2
+IPX_SCOPE_TARGET, IPX_SCOPE_GLOBAL = 0, 1
+IPX_EXCLUDE_MULTI = 1
+IPX_DATA_CIGAR, IPX_DATA_CATEGORY, IPX_DATA_GENOME_MISSING, IPX_DATA_GENOME_SHORT, IPX_DATA_TARGET = 1, 2, 3, 4, 5
+MOTIF_PRESENT, MOTIF_NONACGT, MOTIF_CANON_P, MOTIF_CANON_RC = 0x8000, 0x4000, 0x2000, 0x1000
+
+# every symbol include/ipx.h declares
+SYMBOLS = [
+    "ipx_abi_version", "ipx_create", "ipx_destroy", "ipx_set_targets", "ipx_set_genome_2bit",
+    "ipx_reserve", "ipx_push_batch", "ipx_finalize", "ipx_clear", "ipx_last_error",
+    "ipx_finalize_shard", "ipx_last_timing",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("min_anchor_length", C.c_uint32), ("max_anchor_indel_size", C.c_uint32),
+        ("min_intron_length", C.c_uint32), ("max_intron_length", C.c_uint32),
+        ("sj_filter", C.c_int32), ("strandness", C.c_int32), ("excludes", C.c_uint32),
+        ("scope", C.c_int32), ("skip_missing_targets", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("n_alignments", C.c_uint64), ("n_cigar_words", C.c_uint64), ("base_read_index", C.c_uint64),
+        ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p), ("xs", C.c_void_p),
+        ("nh", C.c_void_p), ("cigar_off", C.c_void_p), ("n_cigar", C.c_void_p), ("cigar", C.c_void_p),
+        ("memory", C.c_int32),
+    ]
+
+
+class Table(C.Structure):
+    _fields_ = [
+        ("n_junctions", C.c_uint64),
+        ("target", C.c_void_p), ("intron_start", C.c_void_p), ("intron_end", C.c_void_p),
+        ("anchor_start", C.c_void_p), ("anchor_end", C.c_void_p), ("strand", C.c_void_p),
+        ("motif", C.c_void_p), ("read_counts", C.c_void_p), ("creator_index", C.c_void_p),
+        ("ijunc", C.c_void_p), ("hist_begin", C.c_void_p), ("hist_value", C.c_void_p),
+        ("hist_count", C.c_void_p), ("n_hist", C.c_uint64),
+        ("n_alignments", C.c_uint64), ("n_records", C.c_uint64), ("memory", C.c_int32),
+    ]
+
+
+class Error(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("kind", C.c_int32), ("read_index", C.c_uint64), ("target", C.c_uint32),
+        ("start", C.c_uint32), ("end", C.c_uint32), ("retlen", C.c_int32), ("op", C.c_char),
+        ("detail", C.c_char * 235),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libipx.so and declare the prototypes.  Loading does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("intronprospector_amd: %s is missing; build it with "
+                          "`make -C intronprospector_amd/csrc` (hipcc, gfx950). There is no CPU fallback."
+                          % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.ipx_abi_version.restype = C.c_uint32
+    lib.ipx_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    lib.ipx_destroy.argtypes = [vp]
+    lib.ipx_set_targets.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]
+    lib.ipx_set_genome_2bit.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                        C.POINTER(vp), C.POINTER(vp)]
+    lib.ipx_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.ipx_push_batch.argtypes = [vp, C.POINTER(Batch)]
+    lib.ipx_finalize.argtypes = [vp, C.c_int32, C.POINTER(Table)]
+    lib.ipx_clear.argtypes = [vp]
+    lib.ipx_last_error.argtypes = [vp, C.POINTER(Error)]
+    lib.ipx_finalize_shard.argtypes = [vp, C.POINTER(Table), C.POINTER(Table)]
+    lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for name in SYMBOLS:
+        getattr(lib, name)
+    _lib = lib
+    return lib

@@ -1,0 +1,672 @@
+// ipx_api.hip -- the C ABI of include/ipx.h: handle, device memory, streams,
+// and the order in which the kernels of ipx_scan/ipx_sort/ipx_reduce run.
+//
+// Stands where the reference's JunctionsExtractor object stands
+// (src/junctions_extractor.hh:73-256): construction with by-value thresholds,
+// a target list, an optional genome, process_alignment over the input, and a
+// junction table handed to the printers.  There is no CPU path in this
+// library: every entry point needs a gfx950 device.
+#include "ipx_common.h"
+#include "ipx_reduce.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct Arena {
+    char *base = nullptr;
+    size_t off = 0, cap = 0;
+    bool measuring = true;
+    template <typename T> T *take(uint64_t count) {
+        const size_t bytes = ((size_t)count * sizeof(T) + 255) & ~(size_t)255;
+        T *r = measuring ? nullptr : (T *)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+}  // namespace
+
+struct ipx_handle {
+    ipx_params params{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // targets
+    std::vector<std::string> names;
+    std::vector<int64_t> target_len;
+    std::vector<uint32_t> rank_of_tid, tid_of_rank;
+    uint32_t n_ranks = 0;
+    DevBuf d_rank_of_tid, d_tid_of_rank;
+    KeyLayout key{};
+    // genome
+    bool have_genome = false;
+    std::vector<std::string> gnames;
+    std::vector<int64_t> glen;
+    DevBuf d_twobit, d_mask, d_seq_len, d_seq_word2, d_seq_wordm, d_seq_of_rank;
+    // records
+    DevBuf items_a, items_b, pays;
+    uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
+    uint64_t seen_words = 0, seen_records = 0;     // for the capacity estimate
+    uint64_t reserved_records = 0;
+    DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small;
+    // pinned host
+    void *pin_small = nullptr;     // 256 bytes of read-back scalars
+    void *pin_out = nullptr;
+    size_t pin_out_cap = 0;
+    ipx_table table{};
+    ipx_error err{};
+    float push_ms = 0.f, fin_ms = 0.f;
+};
+
+namespace {
+
+int fail(ipx_handle *h, int status, const char *fmt, const char *a = "", long b = 0) {
+    if (h) {
+        h->err.status = status;
+        snprintf(h->err.detail, sizeof h->err.detail, fmt, a, b);
+    }
+    return status;
+}
+
+int fail_hip(ipx_handle *h, hipError_t e, const char *what, int line) {
+    if (h) {
+        h->err.status = (e == hipErrorOutOfMemory) ? IPX_ENOMEM : IPX_EDEVICE;
+        snprintf(h->err.detail, sizeof h->err.detail, "%s: %s (ipx_api.hip:%d)", what, hipGetErrorString(e), line);
+        return h->err.status;
+    }
+    return IPX_EDEVICE;
+}
+
+#define HIPCHK(call)                                                  \
+    do {                                                              \
+        hipError_t e__ = (call);                                      \
+        if (e__ != hipSuccess) return fail_hip(h, e__, #call, __LINE__); \
+    } while (0)
+
+int ensure(ipx_handle *h, DevBuf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0) {
+    if (bytes <= b.cap) return IPX_OK;
+    size_t want = keep ? std::max(bytes, b.cap + b.cap / 2) : bytes;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&np, want); }
+    if (e != hipSuccess) return fail_hip(h, e, "hipMalloc", __LINE__);
+    if (keep && b.p && keep_bytes) {
+        e = hipMemcpyAsync(np, b.p, keep_bytes, hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { (void)hipFree(np); return fail_hip(h, e, "hipMemcpy(grow)", __LINE__); }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
+    b.cap = want;
+    return IPX_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+uint32_t bits_for(uint64_t max_value) {
+    uint32_t b = 1;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b;
+}
+
+int compute_layout(ipx_handle *h) {
+    KeyLayout k{};
+    k.len_bits = bits_for(h->params.max_intron_length);
+    k.start_bits = 32;
+    k.rank_bits = bits_for(h->n_ranks ? h->n_ranks - 1 : 0);
+    k.total_bits = 16 + k.len_bits + k.start_bits + k.rank_bits;
+    if (k.total_bits > 96)
+        return fail(h, IPX_EINVAL, "sort key needs %s%ld bits (> 96): too many targets for this max_intron_length", "", (long)k.total_bits);
+    k.n_digits = (k.total_bits + 7) / 8;
+    h->key = k;
+    return IPX_OK;
+}
+
+int upload(ipx_handle *h, DevBuf &b, const void *src, size_t bytes) {
+    int rc = ensure(h, b, bytes ? bytes : 4);
+    if (rc) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return IPX_OK;
+}
+
+int rebuild_ranks(ipx_handle *h) {
+    const uint32_t n = (uint32_t)h->names.size();
+    h->rank_of_tid.assign(n, 0);
+    h->tid_of_rank.clear();
+    if (h->params.scope == IPX_SCOPE_TARGET) {
+        for (uint32_t i = 0; i < n; ++i) { h->rank_of_tid[i] = i; h->tid_of_rank.push_back(i); }
+    } else {
+        // std::map<JunctionKey> orders chromosomes as std::string (junctions.hh:77-83)
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t a, uint32_t b) { return h->names[a] < h->names[b]; });
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t t = order[k];
+            if (k == 0 || h->names[t] != h->names[order[k - 1]]) h->tid_of_rank.push_back(t);   // first tid with the name
+            h->rank_of_tid[t] = (uint32_t)h->tid_of_rank.size() - 1;
+        }
+    }
+    h->n_ranks = (uint32_t)h->tid_of_rank.size();
+    int rc = compute_layout(h);
+    if (rc) return rc;
+    if ((rc = upload(h, h->d_rank_of_tid, h->rank_of_tid.data(), n * sizeof(uint32_t)))) return rc;
+    if ((rc = upload(h, h->d_tid_of_rank, h->tid_of_rank.data(), h->n_ranks * sizeof(uint32_t)))) return rc;
+    // genome sequence per rank
+    if (h->have_genome) {
+        std::vector<int32_t> sor(h->n_ranks ? h->n_ranks : 1, -1);
+        for (uint32_t r = 0; r < h->n_ranks; ++r) {
+            const std::string &nm = h->names[h->tid_of_rank[r]];
+            for (size_t g = 0; g < h->gnames.size(); ++g)
+                if (h->gnames[g] == nm) { sor[r] = (int32_t)g; break; }
+        }
+        if ((rc = upload(h, h->d_seq_of_rank, sor.data(), sor.size() * sizeof(int32_t)))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return IPX_OK;
+}
+
+int reset_counters(ipx_handle *h) {
+    Counters c{};
+    c.n_records = h->n_records;
+    c.err_word = IPX_ERRW_NONE;
+    HIPCHK(hipMemcpyAsync(h->counters.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return IPX_OK;
+}
+
+int grow_records(ipx_handle *h, uint64_t cap) {
+    if (cap <= h->rec_cap) return IPX_OK;
+    if (cap >= (1ull << 32)) return fail(h, IPX_EINVAL, "more than 2^32-1 junction records in one table%s%ld", "", 0);
+    int rc;
+    if ((rc = ensure(h, h->items_a, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, h->pays, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
+    h->rec_cap = std::min(h->items_a.cap, h->pays.cap) / sizeof(uint4);
+    return IPX_OK;
+}
+
+void fill_data_error(ipx_handle *h, unsigned long long w) {
+    ipx_error &e = h->err;
+    e.status = IPX_EDATA;
+    e.read_index = IPX_ORD_READ(w);
+    e.target = 0xffffffffu;
+    const uint32_t kind = (uint32_t)(w >> 8) & 3u, detail = (uint32_t)w & 0xffu;
+    switch (kind) {
+        case IPX_ERRK_CIGAR:
+            e.kind = IPX_DATA_CIGAR;
+            e.op = (char)detail;
+            snprintf(e.detail, sizeof e.detail, "Unknown cigar operation '%c'", (char)detail);
+            break;
+        case IPX_ERRK_GENOME:
+            e.kind = detail ? IPX_DATA_GENOME_SHORT : IPX_DATA_GENOME_MISSING;
+            break;
+        case IPX_ERRK_CATEGORY:
+            e.kind = IPX_DATA_CATEGORY;
+            snprintf(e.detail, sizeof e.detail, "should never look at FQCAIL, FUNMAP, FDUP reads");
+            break;
+        default:
+            e.kind = IPX_DATA_TARGET;
+            snprintf(e.detail, sizeof e.detail, detail ? "more than 2^20-1 junction records in one alignment"
+                                                      : "alignment tid is not a valid target index");
+            break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t ipx_abi_version(void) { return IPX_ABI_VERSION; }
+
+int ipx_create(const ipx_params *params, ipx_handle **out) {
+    if (!params || !out) return IPX_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IPX_ENODEVICE;
+    if (params->device < 0 || params->device >= ndev) return IPX_ENODEVICE;
+    if (hipSetDevice(params->device) != hipSuccess) return IPX_ENODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, params->device) != hipSuccess) return IPX_ENODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return IPX_ENODEVICE;   // code objects are gfx950 only
+    if (params->sj_filter < 0 || params->sj_filter > 2 || params->strandness < 0 || params->strandness > 2 ||
+        params->scope < 0 || params->scope > 1)
+        return IPX_EINVAL;
+    ipx_handle *h = new (std::nothrow) ipx_handle();
+    if (!h) return IPX_ENOMEM;
+    h->params = *params;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
+    for (auto &e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
+    if (hipHostMalloc(&h->pin_small, 256, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
+    int rc = ensure(h, h->counters, sizeof(Counters));
+    if (!rc) rc = ensure(h, h->pass_skip, 16 * sizeof(uint32_t));
+    if (!rc) rc = ensure(h, h->rank_skip, 16 * sizeof(uint32_t));
+    if (!rc) rc = ensure(h, h->d_small, 64 * sizeof(uint32_t));
+    if (!rc) rc = reset_counters(h);
+    if (!rc) rc = rebuild_ranks(h);
+    if (rc) { ipx_destroy(h); return rc; }
+    *out = h;
+    return IPX_OK;
+}
+
+int ipx_destroy(ipx_handle *h) {
+    if (!h) return IPX_OK;
+    (void)hipSetDevice(h->params.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
+                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays,
+                      &h->counters, &h->stage, &h->sort_ws, &h->pass_skip, &h->scratch, &h->out_arena,
+                      &h->rank_skip, &h->d_small})
+        release(*b);
+    if (h->pin_small) (void)hipHostFree(h->pin_small);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    for (auto &e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return IPX_OK;
+}
+
+int ipx_set_targets(ipx_handle *h, uint32_t n, const char *const *names, const int64_t *lengths) {
+    if (!h || (n && !names)) return IPX_EINVAL;
+    if (h->n_records) return fail(h, IPX_EINVAL, "ipx_set_targets with records pending: call ipx_clear first%s%ld", "", 0);
+    (void)hipSetDevice(h->params.device);
+    h->names.clear();
+    h->target_len.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        h->names.emplace_back(names[i] ? names[i] : "");
+        h->target_len.push_back(lengths ? lengths[i] : -1);
+    }
+    return rebuild_ranks(h);
+}
+
+int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names, const int64_t *lengths,
+                        const uint8_t *const *twobit, const uint8_t *const *mask) {
+    if (!h) return IPX_EINVAL;
+    if (n_seqs && (!names || !lengths || !twobit || !mask)) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    h->gnames.clear();
+    h->glen.clear();
+    h->have_genome = n_seqs > 0;
+    if (!h->have_genome) return rebuild_ranks(h);
+    std::vector<uint64_t> w2(n_seqs), wm(n_seqs);
+    uint64_t tot2 = 0, totm = 0;
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        if (lengths[i] < 0) return IPX_EINVAL;
+        h->gnames.emplace_back(names[i]);
+        h->glen.push_back(lengths[i]);
+        w2[i] = tot2; wm[i] = totm;
+        tot2 += ((uint64_t)lengths[i] + 15) / 16;
+        totm += ((uint64_t)lengths[i] + 31) / 32;
+    }
+    int rc;
+    if ((rc = ensure(h, h->d_twobit, (tot2 ? tot2 : 1) * 4))) return rc;
+    if ((rc = ensure(h, h->d_mask, (totm ? totm : 1) * 4))) return rc;
+    HIPCHK(hipMemsetAsync(h->d_twobit.p, 0, (tot2 ? tot2 : 1) * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_mask.p, 0, (totm ? totm : 1) * 4, h->stream));
+    for (uint32_t i = 0; i < n_seqs; ++i) {
+        const uint64_t L = (uint64_t)lengths[i];
+        if (!L) continue;
+        HIPCHK(hipMemcpyAsync(h->d_twobit.as<uint32_t>() + w2[i], twobit[i], (L + 3) / 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_mask.as<uint32_t>() + wm[i], mask[i], (L + 7) / 8, hipMemcpyHostToDevice, h->stream));
+    }
+    if ((rc = upload(h, h->d_seq_len, h->glen.data(), n_seqs * sizeof(int64_t)))) return rc;
+    if ((rc = upload(h, h->d_seq_word2, w2.data(), n_seqs * sizeof(uint64_t)))) return rc;
+    if ((rc = upload(h, h->d_seq_wordm, wm.data(), n_seqs * sizeof(uint64_t)))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));      // caller memory is borrowed until return
+    return rebuild_ranks(h);
+}
+
+int ipx_reserve(ipx_handle *h, uint64_t n_alignments, uint64_t n_cigar_words, uint64_t n_records) {
+    if (!h) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    int rc;
+    if ((rc = ensure(h, h->stage, n_alignments * 20 + n_cigar_words * 4 + 8 * 256))) return rc;
+    h->reserved_records = n_records;
+    if ((rc = grow_records(h, h->n_records + n_records))) return rc;
+    if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, h->sort_ws, ipx_sort_workspace_bytes(h->rec_cap)))) return rc;
+    return IPX_OK;
+}
+
+int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
+    if (!h || !b) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    const uint64_t n = b->n_alignments, nw = b->n_cigar_words;
+    if (n == 0) return IPX_OK;
+    if (!b->tid || !b->pos || !b->flag || !b->xs || !b->nh || !b->cigar_off || !b->n_cigar || (nw && !b->cigar))
+        return fail(h, IPX_EINVAL, "ipx_push_batch: null array%s%ld", "", 0);
+    if (b->base_read_index + n > IPX_ORD_MAX_READ)
+        return fail(h, IPX_EINVAL, "read index beyond 2^34-1%s%ld", "", 0);
+    if (nw >= (1ull << 32)) return fail(h, IPX_EINVAL, "more than 2^32-1 CIGAR words in one batch%s%ld", "", 0);
+    int rc;
+    ipx_batch db = *b;
+    if (b->memory == IPX_MEM_HOST) {
+        // one staging buffer, 256-byte aligned sections
+        auto al = [](uint64_t x) { return (x + 255) & ~255ull; };
+        const uint64_t o_tid = 0, o_pos = al(o_tid + n * 4), o_flag = al(o_pos + n * 4), o_xs = al(o_flag + n * 2),
+                       o_nh = al(o_xs + n), o_off = al(o_nh + n), o_nc = al(o_off + n * 4), o_cig = al(o_nc + n * 4),
+                       total = al(o_cig + nw * 4);
+        if ((rc = ensure(h, h->stage, total))) return rc;
+        char *s = h->stage.as<char>();
+        HIPCHK(hipMemcpyAsync(s + o_tid, b->tid, n * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s + o_pos, b->pos, n * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s + o_flag, b->flag, n * 2, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s + o_xs, b->xs, n, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s + o_nh, b->nh, n, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s + o_off, b->cigar_off, n * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(s + o_nc, b->n_cigar, n * 4, hipMemcpyHostToDevice, h->stream));
+        if (nw) HIPCHK(hipMemcpyAsync(s + o_cig, b->cigar, nw * 4, hipMemcpyHostToDevice, h->stream));
+        db.tid = (const int32_t *)(s + o_tid); db.pos = (const int32_t *)(s + o_pos);
+        db.flag = (const uint16_t *)(s + o_flag); db.xs = (const uint8_t *)(s + o_xs);
+        db.nh = (const uint8_t *)(s + o_nh); db.cigar_off = (const uint32_t *)(s + o_off);
+        db.n_cigar = (const uint32_t *)(s + o_nc); db.cigar = (const uint32_t *)(s + o_cig);
+    } else if (b->memory != IPX_MEM_DEVICE) {
+        return IPX_EINVAL;
+    }
+
+    // capacity: a record needs at least two CIGAR words (xM yN zM -> 1 record per extra 2 words)
+    const uint64_t upper = nw / 2;
+    uint64_t guess = 2 * n + 1024;
+    if (h->seen_words) guess = std::max<uint64_t>(guess, (uint64_t)((double)h->seen_records / (double)h->seen_words * (double)nw * 1.25) + 1024);
+    uint64_t want = h->n_records + std::min(upper, guess);
+    if ((rc = grow_records(h, want))) return rc;
+
+    ScanParams sp{};
+    sp.min_anchor_length = h->params.min_anchor_length;
+    sp.max_anchor_indel_size = h->params.max_anchor_indel_size;
+    sp.min_intron_length = h->params.min_intron_length;
+    sp.max_intron_length = h->params.max_intron_length;
+    sp.strandness = h->params.strandness;
+    sp.exclude_multi = (h->params.excludes & IPX_EXCLUDE_MULTI) ? 1u : 0u;
+    sp.n_targets = (uint32_t)h->names.size();
+    sp.key = h->key;
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(hipEventRecord(h->ev[0], h->stream));
+        HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                               h->pays.as<uint4>(), h->rec_cap, h->counters.as<Counters>()));
+        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const Counters *c = (const Counters *)h->pin_small;
+        if (c->n_records <= h->rec_cap) {
+            h->seen_words += nw;
+            h->seen_records += c->n_records - h->n_records;
+            h->n_records = c->n_records;
+            break;
+        }
+        // the estimate was too small: records beyond the capacity were counted but not
+        // stored.  Make room for exactly what this batch needs and scan it again.
+        if (attempt == 1) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
+        const uint64_t need = c->n_records;
+        Counters reset = *c;
+        reset.n_records = h->n_records;
+        HIPCHK(hipMemcpyAsync(h->counters.p, &reset, sizeof reset, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = grow_records(h, need))) return rc;
+    }
+    (void)hipEventElapsedTime(&h->push_ms, h->ev[0], h->ev[1]);
+    h->n_alignments += n;
+    return IPX_OK;
+}
+
+int ipx_clear(ipx_handle *h) {
+    if (!h) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    h->n_records = 0;
+    h->n_alignments = 0;
+    memset(&h->table, 0, sizeof h->table);
+    return reset_counters(h);
+}
+
+int ipx_last_error(const ipx_handle *h, ipx_error *out) {
+    if (!h || !out) return IPX_EINVAL;
+    *out = h->err;
+    return IPX_OK;
+}
+
+int ipx_last_timing(const ipx_handle *h, float *push_ms, float *finalize_ms) {
+    if (!h) return IPX_EINVAL;
+    if (push_ms) *push_ms = h->push_ms;
+    if (finalize_ms) *finalize_ms = h->fin_ms;
+    return IPX_OK;
+}
+
+int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
+    if (!h || !out || (memory != IPX_MEM_HOST && memory != IPX_MEM_DEVICE)) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    memset(out, 0, sizeof *out);
+    memset(&h->err, 0, sizeof h->err);
+    const uint64_t R = h->n_records;
+    int rc;
+    hipStream_t s = h->stream;
+    uint32_t *small = (uint32_t *)h->pin_small;
+    uint32_t J = 0, B = 0, n_valid = 0, n_hist = 0;
+    ReduceBuffers rb{};
+    unsigned long long err_word = IPX_ERRW_NONE;
+
+    HIPCHK(hipEventRecord(h->ev[2], s));
+    if (R > 0) {
+        // one workspace serves the sort (digit histograms) and, once the sort is done,
+        // the per-chunk head counts of the reduce
+        const uint64_t chunks = ipx_reduce_chunks(R);
+        const uint64_t chunks_al = (chunks + 63) & ~63ull;
+        const uint64_t sums1 = ipx_div_up(chunks, 4096) + 2;
+        const size_t ws_bytes = std::max(ipx_sort_workspace_bytes(R),
+                                         (size_t)((2 * chunks_al + sums1) * sizeof(uint32_t) + 1024));
+        if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
+        if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
+        HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), R, h->key.n_digits,
+                               h->sort_ws.p, h->sort_ws.cap, h->pass_skip.as<uint32_t>()));
+        SortedItems si{h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->pass_skip.as<uint32_t>(), h->key.n_digits, R};
+
+        uint32_t *chunk_j = h->sort_ws.as<uint32_t>();
+        uint32_t *chunk_b = chunk_j + chunks_al;
+        uint32_t *sums = chunk_b + chunks_al;
+        uint32_t *tot = h->d_small.as<uint32_t>();
+        HIPCHK(ipx_launch_count_heads(s, si, chunk_j, chunk_b));
+        HIPCHK(ipx_launch_scan_u32(s, chunk_j, chunk_j, chunks, sums, tot + 0));
+        HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
+        HIPCHK(hipMemcpyAsync(small, tot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        J = small[0];
+        B = small[1];
+
+        // stage 2: scratch and output sections, laid out twice (measure, then place)
+        uint32_t *detail4 = nullptr;
+        void *rank_ws = nullptr;
+        auto layout = [&](Arena &tmp, Arena &outa) {
+            rb.chunk_j = chunk_j; rb.chunk_b = chunk_b; rb.n_j = J; rb.n_b = B;
+            rb.jrank = tmp.take<uint32_t>(J); rb.jstart = tmp.take<uint32_t>(J); rb.jend = tmp.take<uint32_t>(J);
+            rb.jmotif = tmp.take<uint32_t>(J); rb.amin = tmp.take<uint32_t>(J); rb.amax = tmp.take<uint32_t>(J);
+            rb.jvalid = tmp.take<uint32_t>(J); rb.jpos = tmp.take<uint32_t>(J); rb.jnb = tmp.take<uint32_t>(J);
+            rb.jstrand = tmp.take<uint8_t>(J);
+            rb.first = tmp.take<unsigned long long>(J); rb.creator = tmp.take<unsigned long long>(J);
+            rb.counts = tmp.take<unsigned long long>(3ull * J);
+            rb.bin_j = tmp.take<uint32_t>(B); rb.bin_off = tmp.take<uint32_t>(B); rb.bin_count = tmp.take<uint32_t>(B);
+            rb.bin_flag = tmp.take<uint32_t>(B); rb.bin_pos = tmp.take<uint32_t>(B);
+            rb.scan_sums = tmp.take<uint32_t>(ipx_div_up(std::max<uint64_t>(std::max(J, B), 1), 4096) + 2);
+            rb.totals = tmp.take<uint32_t>(64);
+            rb.rank_a = tmp.take<uint4>(J); rb.rank_b = tmp.take<uint4>(J);
+            detail4 = tmp.take<uint32_t>(64);
+            rank_ws = tmp.take<char>(ipx_sort_workspace_bytes(J));
+            rb.out_target = outa.take<uint32_t>(J); rb.out_intron_start = outa.take<uint32_t>(J);
+            rb.out_intron_end = outa.take<uint32_t>(J); rb.out_anchor_start = outa.take<uint32_t>(J);
+            rb.out_anchor_end = outa.take<uint32_t>(J); rb.out_strand = outa.take<uint8_t>(J);
+            rb.out_motif = outa.take<uint16_t>(J); rb.out_read_counts = outa.take<uint64_t>(3ull * J);
+            rb.out_creator_index = outa.take<uint64_t>(J); rb.out_hist_begin = outa.take<uint64_t>((uint64_t)J + 1);
+            rb.out_ijunc = outa.take<uint32_t>(J); rb.out_hist_value = outa.take<uint16_t>(B);
+            rb.out_hist_count = outa.take<uint32_t>(B);
+        };
+        {
+            Arena tmp, outa;
+            layout(tmp, outa);
+            if ((rc = ensure(h, h->scratch, tmp.off + 256))) return rc;
+            if ((rc = ensure(h, h->out_arena, outa.off + 256))) return rc;
+            Arena tmp2, outa2;
+            tmp2.measuring = outa2.measuring = false;
+            tmp2.base = h->scratch.as<char>();
+            outa2.base = h->out_arena.as<char>();
+            layout(tmp2, outa2);
+        }
+        GenomeDev g{};
+        if (h->have_genome) {
+            g.twobit = h->d_twobit.as<uint32_t>(); g.mask = h->d_mask.as<uint32_t>();
+            g.seq_len = h->d_seq_len.as<int64_t>(); g.seq_word2 = h->d_seq_word2.as<uint64_t>();
+            g.seq_wordm = h->d_seq_wordm.as<uint64_t>(); g.seq_of_rank = h->d_seq_of_rank.as<int32_t>();
+        }
+        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->key, rb, g, h->params.sj_filter,
+                                 h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
+                                 h->counters.as<Counters>()));
+        HIPCHK(hipMemcpyAsync(small, rb.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(small + 4, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        n_valid = small[0];
+        n_hist = small[1];
+        err_word = ((const Counters *)(small + 4))->err_word;
+        // ijunc: rank of the creation order (junctions_extractor.cc:459-460)
+        if (n_valid) {
+            HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, n_valid, 7, rank_ws, ipx_sort_workspace_bytes(J),
+                                   h->rank_skip.as<uint32_t>()));
+            HIPCHK(ipx_launch_emit_ijunc(s, n_valid, rb.rank_a, rb.rank_b, h->rank_skip.as<uint32_t>(), 7,
+                                         rb.out_ijunc));
+        }
+        if (err_word != IPX_ERRW_NONE && ((err_word >> 8) & 3u) == IPX_ERRK_GENOME) {
+            HIPCHK(hipMemsetAsync(detail4, 0, 16, s));
+            HIPCHK(ipx_launch_find_genome_error(s, J, rb.first, rb.jmotif, rb.jrank, rb.jstart, rb.jend,
+                                                IPX_ORD_SEQ(err_word), detail4));
+            HIPCHK(hipMemcpyAsync(small + 16, detail4, 16, hipMemcpyDeviceToHost, s));
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(small + 4, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        err_word = ((const Counters *)(small + 4))->err_word;
+    }
+    HIPCHK(hipEventRecord(h->ev[3], s));
+
+    ipx_table t{};
+    t.n_junctions = n_valid;
+    t.n_hist = n_hist;
+    t.n_alignments = h->n_alignments;
+    t.n_records = R;
+    t.memory = memory;
+    if (memory == IPX_MEM_DEVICE || R == 0) {
+        t.target = rb.out_target; t.intron_start = rb.out_intron_start; t.intron_end = rb.out_intron_end;
+        t.anchor_start = rb.out_anchor_start; t.anchor_end = rb.out_anchor_end; t.strand = rb.out_strand;
+        t.motif = rb.out_motif; t.read_counts = rb.out_read_counts; t.creator_index = rb.out_creator_index;
+        t.ijunc = rb.out_ijunc; t.hist_begin = rb.out_hist_begin; t.hist_value = rb.out_hist_value;
+        t.hist_count = rb.out_hist_count;
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        // pinned host copy, same section layout
+        Arena ha;
+        ha.measuring = true;
+        for (int pass = 0; pass < 2; ++pass) {
+            ha.off = 0;
+            ha.measuring = (pass == 0);
+            ha.base = (char *)h->pin_out;
+            uint32_t *p_target = ha.take<uint32_t>(n_valid), *p_is = ha.take<uint32_t>(n_valid),
+                     *p_ie = ha.take<uint32_t>(n_valid), *p_as = ha.take<uint32_t>(n_valid),
+                     *p_ae = ha.take<uint32_t>(n_valid);
+            uint8_t *p_strand = ha.take<uint8_t>(n_valid);
+            uint16_t *p_motif = ha.take<uint16_t>(n_valid);
+            uint64_t *p_counts = ha.take<uint64_t>(3ull * n_valid), *p_creator = ha.take<uint64_t>(n_valid),
+                     *p_hb = ha.take<uint64_t>((uint64_t)n_valid + 1);
+            uint32_t *p_ijunc = ha.take<uint32_t>(n_valid);
+            uint16_t *p_hv = ha.take<uint16_t>(n_hist);
+            uint32_t *p_hc = ha.take<uint32_t>(n_hist);
+            if (pass == 0) {
+                if (ha.off + 256 > h->pin_out_cap) {
+                    if (h->pin_out) (void)hipHostFree(h->pin_out);
+                    h->pin_out = nullptr;
+                    h->pin_out_cap = 0;
+                    HIPCHK(hipHostMalloc(&h->pin_out, ha.off + 256, hipHostMallocDefault));
+                    h->pin_out_cap = ha.off + 256;
+                }
+                continue;
+            }
+#define D2H(dst, src, count, T) \
+    if (count) HIPCHK(hipMemcpyAsync(dst, src, (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, s))
+            D2H(p_target, rb.out_target, n_valid, uint32_t);
+            D2H(p_is, rb.out_intron_start, n_valid, uint32_t);
+            D2H(p_ie, rb.out_intron_end, n_valid, uint32_t);
+            D2H(p_as, rb.out_anchor_start, n_valid, uint32_t);
+            D2H(p_ae, rb.out_anchor_end, n_valid, uint32_t);
+            D2H(p_strand, rb.out_strand, n_valid, uint8_t);
+            D2H(p_motif, rb.out_motif, n_valid, uint16_t);
+            D2H(p_counts, rb.out_read_counts, 3ull * n_valid, uint64_t);
+            D2H(p_creator, rb.out_creator_index, n_valid, uint64_t);
+            D2H(p_hb, rb.out_hist_begin, (uint64_t)n_valid + 1, uint64_t);
+            D2H(p_ijunc, rb.out_ijunc, n_valid, uint32_t);
+            D2H(p_hv, rb.out_hist_value, n_hist, uint16_t);
+            D2H(p_hc, rb.out_hist_count, n_hist, uint32_t);
+#undef D2H
+            HIPCHK(hipStreamSynchronize(s));
+            t.target = p_target; t.intron_start = p_is; t.intron_end = p_ie; t.anchor_start = p_as;
+            t.anchor_end = p_ae; t.strand = p_strand; t.motif = p_motif; t.read_counts = p_counts;
+            t.creator_index = p_creator; t.ijunc = p_ijunc; t.hist_begin = p_hb; t.hist_value = p_hv;
+            t.hist_count = p_hc;
+        }
+    }
+    (void)hipEventElapsedTime(&h->fin_ms, h->ev[2], h->ev[3]);
+    h->table = t;
+    *out = t;
+    if (err_word != IPX_ERRW_NONE) {
+        fill_data_error(h, err_word);
+        if (h->err.kind == IPX_DATA_GENOME_MISSING || h->err.kind == IPX_DATA_GENOME_SHORT) {
+            const uint32_t *d4 = small + 16;
+            const uint32_t rank = d4[0];
+            h->err.target = (rank < h->tid_of_rank.size()) ? h->tid_of_rank[rank] : 0xffffffffu;
+            // the acceptor side [end-2,end) is fetched first (GCC argument order); it is the
+            // failing fetch unless only the donor side runs off the end (cannot happen: start < end)
+            const int64_t e = (int64_t)(int32_t)d4[2], st = (int64_t)(int32_t)d4[1];
+            int64_t L = -1;
+            if (h->err.target != 0xffffffffu) {
+                const std::string &nm = h->names[h->err.target];
+                for (size_t g = 0; g < h->gnames.size(); ++g)
+                    if (h->gnames[g] == nm) { L = h->glen[g]; break; }
+            }
+            auto clamp_len = [&](int64_t beg, int64_t endi) -> int64_t {   // faidx_adjust_position
+                if (endi < beg) beg = endi;
+                if (beg < 0) beg = 0; else if (L <= beg) beg = L;
+                if (endi < 0) endi = 0; else if (L <= endi) endi = L - 1;
+                return endi + 1 - beg > 0 ? endi + 1 - beg : 0;
+            };
+            int64_t fs = e - 2, fe = e;
+            int64_t got = (L >= 0) ? clamp_len(fs, fe - 1) : -2;
+            if (L >= 0 && got == 2) { fs = st; fe = st + 2; got = clamp_len(fs, fe - 1); }
+            h->err.start = (uint32_t)fs;
+            h->err.end = (uint32_t)fe;
+            h->err.retlen = (int32_t)got;
+            const char *nm = (h->err.target != 0xffffffffu) ? h->names[h->err.target].c_str() : "?";
+            if (h->err.kind == IPX_DATA_GENOME_MISSING)
+                snprintf(h->err.detail, sizeof h->err.detail, "can't load genome sequence for: %s:%d-%d", nm, (int)fs, (int)fe);
+            else
+                snprintf(h->err.detail, sizeof h->err.detail, "unexpected length returned for: %s:%d-%d: %d", nm, (int)fs, (int)fe, (int)got);
+        }
+        return IPX_EDATA;
+    }
+    return IPX_OK;
+}
+
+int ipx_finalize_shard(ipx_handle *h, ipx_table *out_from_creator, ipx_table *out_all) {
+    (void)out_from_creator; (void)out_all;
+    return fail(h, IPX_EINVAL, "ipx_finalize_shard: not implemented yet%s%ld", "", 0);
+}
+
+}  // extern "C"

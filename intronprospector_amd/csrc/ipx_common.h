@@ -1,0 +1,94 @@
+// ipx_common.h -- shared device-side types of libipx (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ipx.h"
+
+#define IPX_WAVE 64
+
+// ---- junction record ------------------------------------------------------
+// One QC-passed junction record is 32 bytes in HBM, split in two 16-byte
+// halves so that the sort moves only the first:
+//
+//   item  (uint4)  k0,k1,k2 = 96-bit sort key, little end first; w = record index
+//   pay   (uint4)  x,y = order64 ; z = anchor_start ; w = anchor_end
+//
+// key bits, low to high:  off16:16 | len:LB | start:SB | rank:RB     (<= 96)
+//   off16 = uint16(intron_start - pos)            junctions.hh:163-167
+//   len   = intron_end - intron_start  (<= max_intron_length after junction_qc)
+//   start = uint32(intron_start)                  junctions.hh:57-67
+//   rank  = tid (target scope) or rank of the chromosome name (global scope)
+// key >> 16 is the JunctionKey, ordered as junctions.hh:77-100.
+//
+// order64 = read_index:34 << 30 | ordinal:20 << 10 | strand:8 << 2 | cat:2
+//   read_index = position of the alignment in the run, ordinal = number of the
+//   record inside the alignment: (read_index, ordinal) is the order in which the
+//   reference's sequential loop would have called record_junction().
+//   strand = the READ's junction strand (junctions_extractor.cc:362-371)
+//   cat    = ReadCategory (junctions.hh:49-53) or 3 = get_read_category would
+//            throw (junctions_extractor.cc:73-74)
+#define IPX_ORD_SHIFT_READ 30
+#define IPX_ORD_SHIFT_ORDINAL 10
+#define IPX_ORD_MAX_ORDINAL ((1u << 20) - 1)
+#define IPX_ORD_MAX_READ ((1ull << 34) - 1)
+#define IPX_ORD_SEQ(o) ((o) >> IPX_ORD_SHIFT_ORDINAL)      // (read_index, ordinal)
+#define IPX_ORD_READ(o) ((o) >> IPX_ORD_SHIFT_READ)
+#define IPX_ORD_STRAND(o) ((uint32_t)((o) >> 2) & 0xffu)
+#define IPX_ORD_CAT(o) ((uint32_t)(o) & 3u)
+
+// error word, same ordering as order64 so that min() is "earliest in input
+// order":  read_index:34 << 30 | ordinal:20 << 10 | kind:2 << 8 | detail:8
+// kind 0 sorts before a record's own errors at the same ordinal: a CIGAR error
+// met after m records were emitted carries ordinal m.
+#define IPX_ERRW_NONE 0xffffffffffffffffull
+#define IPX_ERRK_CIGAR 0u
+#define IPX_ERRK_GENOME 1u   // detail: 0 = missing sequence, 1 = short fetch
+#define IPX_ERRK_CATEGORY 2u
+#define IPX_ERRK_TARGET 3u
+
+struct KeyLayout {
+    uint32_t len_bits, start_bits, rank_bits;   // off16 is always 16
+    uint32_t total_bits, n_digits;              // 8-bit digits
+};
+
+struct ScanParams {
+    uint32_t min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length;
+    int32_t strandness;
+    uint32_t exclude_multi;
+    uint32_t n_targets;
+    KeyLayout key;
+};
+
+// device-side counters of one handle (one cache line apart is not needed: they
+// are touched once per wave at most)
+struct Counters {
+    unsigned long long n_records;      // allocated so far (may exceed capacity)
+    unsigned long long err_word;       // earliest data error, IPX_ERRW_NONE if none
+    unsigned long long n_reads_scanned;
+};
+
+struct GenomeDev {
+    const uint32_t *twobit;      // 16 bases per word, all sequences concatenated (word aligned per sequence)
+    const uint32_t *mask;        // 32 bases per word
+    const int64_t *seq_len;      // per genome sequence
+    const uint64_t *seq_word2;   // first twobit word of the sequence
+    const uint64_t *seq_wordm;   // first mask word of the sequence
+    const int32_t *seq_of_rank;  // per key rank: genome sequence index, -1 = missing, -2 = no genome
+};
+
+static inline uint64_t ipx_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ---- launchers implemented in the kernel translation units -------------------
+// ipx_scan.hip
+hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
+                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays,
+                           uint64_t capacity, Counters *counters);
+
+// ipx_sort.hip
+size_t ipx_sort_workspace_bytes(uint64_t n);
+hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint64_t n, uint32_t n_digits,
+                           void *workspace, size_t workspace_bytes, uint32_t *pass_skip /* dev, 16 words */);
+// in == out allowed; block_sums needs div_up(n,4096)+1 words; total may be NULL
+hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
+                               uint32_t *block_sums, uint32_t *total);

@@ -1,0 +1,45 @@
+// ipx_reduce.h -- buffers and launchers of the segmented reduce (ipx_reduce.hip).
+#pragma once
+#include "ipx_common.h"
+
+struct SortedItems {
+    const uint4 *a, *b;           // ping-pong buffers of the radix sort
+    const uint32_t *pass_skip;    // device: which passes were dropped -> which buffer holds the result
+    uint32_t n_digits;
+    uint64_t n;
+};
+
+struct ReduceBuffers {
+    // per 512-record chunk, exclusive prefix of segment heads
+    uint32_t *chunk_j, *chunk_b;
+    uint32_t n_j, n_b;            // junction keys / (key, off16) bins before filtering
+    // per junction key (n_j)
+    uint32_t *jrank, *jstart, *jend, *jmotif, *amin, *amax, *jvalid, *jpos, *jnb;
+    uint8_t *jstrand;
+    unsigned long long *first, *creator, *counts;
+    // per bin (n_b)
+    uint32_t *bin_j, *bin_off, *bin_count, *bin_flag, *bin_pos;
+    uint32_t *scan_sums;          // >= div_up(max(n_j, n_b), 4096) + 1
+    uint32_t *totals;             // [0] valid junctions, [1] non-empty bins
+    // outputs (device), sized n_j / n_b
+    uint32_t *out_target, *out_intron_start, *out_intron_end, *out_anchor_start, *out_anchor_end;
+    uint8_t *out_strand;
+    uint16_t *out_motif;
+    uint64_t *out_read_counts, *out_creator_index, *out_hist_begin;
+    uint32_t *out_ijunc;
+    uint16_t *out_hist_value;
+    uint32_t *out_hist_count;
+    uint4 *rank_a, *rank_b;       // creation-order sort for ijunc (n_j)
+};
+
+uint64_t ipx_reduce_chunks(uint64_t n);
+hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b);
+hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const KeyLayout &kl,
+                             const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
+                             int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters);
+hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *a, const uint4 *b,
+                                 const uint32_t *pass_skip, uint32_t n_digits, uint32_t *ijunc);
+hipError_t ipx_launch_find_genome_error(hipStream_t s, uint32_t n_j, const unsigned long long *first,
+                                        const uint32_t *jmotif, const uint32_t *jrank,
+                                        const uint32_t *jstart, const uint32_t *jend,
+                                        unsigned long long err_seq, uint32_t *detail4 /* rank,start,end,found */);

@@ -1,0 +1,533 @@
+// ipx_reduce.hip -- segmented reduce of the sorted junction records into the
+// junction table, with the order-dependent semantics of the reference's
+// sequential map insert/update restated as order-independent reductions:
+//
+//   add_junction      junctions_extractor.cc:488-506   new key: filter decides;
+//                     a record that fails leaves no trace and the next record of
+//                     the key is tried with ITS strand
+//   get_splice_sites  junctions_extractor.cc:405-428   (device 2-bit genome)
+//   correct_strand    junctions_extractor.cc:431-444
+//   junction_filter_check  splice_juncs.cc:52-61
+//   create_junction   junctions_extractor.cc:446-464   creator fixes strand/motif
+//   update_junction   junctions_extractor.cc:466-485   min/max anchors, count_read
+//   Junction::count_read junctions.hh:163-167          counts by category, offsets
+//
+// For one key, with records in input order r0 < r1 < ...: the creator is the
+// first record whose strand passes the filter against the key's motif; records
+// before it are dropped, every record from it on is counted.  So
+//   phase A: creator[key] = min order over passing records (segmented min)
+//   phase B: tallies over records with order >= creator[key] (segmented sums)
+// Records arrive sorted by (key, off16): a key's records are one contiguous
+// segment and, inside it, equal offsets are contiguous runs (histogram bins).
+//
+// Work split: one wavefront per chunk of 512 consecutive sorted records, 8
+// coalesced rounds of 64; segment ids come from per-chunk head counts that were
+// prefix-summed once (k_count_heads + scan), so no per-record id array is stored.
+#include "ipx_common.h"
+
+namespace {
+
+constexpr uint32_t CHUNK = 512;
+constexpr uint32_t ROUNDS = CHUNK / 64;
+constexpr unsigned long long NONE64 = 0xffffffffffffffffull;
+
+__device__ __forceinline__ const uint4 *sorted_buf(const uint4 *a, const uint4 *b,
+                                                   const uint32_t *pass_skip, uint32_t n_digits) {
+    uint32_t par = 0;
+    for (uint32_t k = 0; k < n_digits; ++k) par ^= (pass_skip[k] ? 0u : 1u);
+    return par ? b : a;
+}
+
+struct Heads {
+    bool ok, head_j, head_b;
+    uint4 it;
+};
+
+// flags of item i (lane-parallel inside one round)
+__device__ __forceinline__ Heads load_heads(const uint4 *__restrict__ items, uint64_t i, uint64_t n,
+                                            uint32_t lane) {
+    Heads h;
+    h.ok = i < n;
+    h.it = h.ok ? items[i] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    uint32_t px = __shfl_up(h.it.x, 1), py = __shfl_up(h.it.y, 1), pz = __shfl_up(h.it.z, 1);
+    if (lane == 0 && h.ok && i > 0) {
+        const uint4 p = items[i - 1];
+        px = p.x; py = p.y; pz = p.z;
+    }
+    const bool first = (i == 0);
+    const bool dj = ((px >> 16) != (h.it.x >> 16)) || (py != h.it.y) || (pz != h.it.z);
+    const bool db = dj || ((px & 0xffffu) != (h.it.x & 0xffffu));
+    h.head_j = h.ok && (first || dj);
+    h.head_b = h.ok && (first || db);
+    return h;
+}
+
+__global__ __launch_bounds__(256) void k_count_heads(const uint4 *a, const uint4 *b,
+                                                     const uint32_t *pass_skip, uint32_t n_digits,
+                                                     uint64_t n, uint32_t *__restrict__ chunk_j,
+                                                     uint32_t *__restrict__ chunk_b) {
+    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t base = chunk * CHUNK;
+    if (base >= n) return;
+    uint32_t cj = 0, cb = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
+        cj += (uint32_t)__popcll(__ballot(h.head_j));
+        cb += (uint32_t)__popcll(__ballot(h.head_b));
+    }
+    if (lane == 0) { chunk_j[chunk] = cj; chunk_b[chunk] = cb; }
+}
+
+struct KeyParts { uint32_t rank, start, end, off16; };
+
+__device__ __forceinline__ KeyParts unpack_key(const uint4 &it, const KeyLayout &kl) {
+    const uint64_t lo = (uint64_t)it.x | ((uint64_t)it.y << 32);
+    const uint64_t hi = it.z;
+    KeyParts k;
+    k.off16 = (uint32_t)lo & 0xffffu;
+    const uint32_t len = (uint32_t)((lo >> 16) & ((kl.len_bits >= 32) ? 0xffffffffull : ((1ull << kl.len_bits) - 1)));
+    const uint32_t s1 = 16 + kl.len_bits, s2 = s1 + 32;
+    uint64_t st = lo >> s1;
+    if (s1 > 32) st |= hi << (64 - s1);
+    k.start = (uint32_t)st;
+    uint64_t rk = (s2 < 64) ? ((lo >> s2) | (hi << (64 - s2))) : (hi >> (s2 - 64));
+    k.rank = (uint32_t)(rk & ((kl.rank_bits >= 32) ? 0xffffffffull : ((1ull << kl.rank_bits) - 1)));
+    k.end = k.start + len;
+    return k;
+}
+
+// junction / bin descriptors at the segment heads
+__global__ __launch_bounds__(256) void k_write_heads(const uint4 *a, const uint4 *b,
+                                                     const uint32_t *pass_skip, uint32_t n_digits,
+                                                     uint64_t n, KeyLayout kl,
+                                                     const uint32_t *__restrict__ chunk_j,
+                                                     const uint32_t *__restrict__ chunk_b,
+                                                     uint32_t *__restrict__ jrank,
+                                                     uint32_t *__restrict__ jstart,
+                                                     uint32_t *__restrict__ jend,
+                                                     uint32_t *__restrict__ bin_j,
+                                                     uint32_t *__restrict__ bin_off) {
+    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lane_le = ~0ull >> (63 - lane);
+    const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t base = chunk * CHUNK;
+    if (base >= n) return;
+    uint32_t nj = chunk_j[chunk], nb = chunk_b[chunk];     // heads before this chunk
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
+        const uint64_t mj = __ballot(h.head_j), mb = __ballot(h.head_b);
+        const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
+        const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
+        if (h.head_b) {
+            const KeyParts k = unpack_key(h.it, kl);
+            bin_j[bid] = jid;
+            bin_off[bid] = k.off16;
+            if (h.head_j) { jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; }
+        }
+        nj += (uint32_t)__popcll(mj);
+        nb += (uint32_t)__popcll(mb);
+    }
+}
+
+// ---- genome -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t base2(const GenomeDev &g, uint64_t w0, int64_t p) {
+    return (g.twobit[w0 + (uint64_t)(p >> 4)] >> ((p & 15) * 2)) & 3u;
+}
+__device__ __forceinline__ uint32_t maskbit(const GenomeDev &g, uint64_t w0, int64_t p) {
+    return (g.mask[w0 + (uint64_t)(p >> 5)] >> (p & 31)) & 1u;
+}
+
+// splice_juncs.cc:22-26 on 2-bit codes A0 C1 G2 T3: GT/AG, GC/AG, AT/AC
+__device__ __forceinline__ bool canon4(uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1) {
+    const bool gt_ag = (d0 == 2 && d1 == 3 && a0 == 0 && a1 == 2);
+    const bool gc_ag = (d0 == 2 && d1 == 1 && a0 == 0 && a1 == 2);
+    const bool at_ac = (d0 == 0 && d1 == 3 && a0 == 0 && a1 == 1);
+    return gt_ag || gc_ag || at_ac;
+}
+
+// jmotif: IPX_MOTIF_* bits | bases; error marker in bits 11..8:
+//   0x100 = sequence missing and not skippable, 0x200 = fetch ran past the end
+__global__ __launch_bounds__(256) void k_motif(uint32_t n_j, GenomeDev g, int32_t skip_missing,
+                                               const uint32_t *__restrict__ jrank,
+                                               const uint32_t *__restrict__ jstart,
+                                               const uint32_t *__restrict__ jend,
+                                               uint32_t *__restrict__ jmotif) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_j) return;
+    const int32_t seq = g.seq_of_rank ? g.seq_of_rank[jrank[j]] : -2;
+    uint32_t m = 0;
+    if (seq == -2) {
+        m = 0;                                   // no genome: splice_sites == ""
+    } else if (seq < 0) {
+        m = skip_missing ? 0u : 0x100u;          // :411-417 / genome.cc:65-67
+    } else {
+        const int64_t L = g.seq_len[seq];
+        const int64_t s = (int64_t)(int32_t)jstart[j], e = (int64_t)(int32_t)jend[j];   // Genome::fetch takes int
+        // faidx clamps to the sequence; a fetch that returns fewer than 2 bases throws (genome.cc:68-70).
+        // acceptor [e-2,e) is fetched first (see oracle/ipxo_core.c get_splice_sites)
+        if (e - 2 < 0 || e > L || s < 0 || s + 2 > L) {
+            m = 0x200u;
+        } else {
+            const uint64_t w2 = g.seq_word2[seq], wm = g.seq_wordm[seq];
+            const uint32_t d0 = base2(g, w2, s), d1 = base2(g, w2, s + 1);
+            const uint32_t a0 = base2(g, w2, e - 2), a1 = base2(g, w2, e - 1);
+            const uint32_t non = maskbit(g, wm, s) | maskbit(g, wm, s + 1) | maskbit(g, wm, e - 2) |
+                                 maskbit(g, wm, e - 1);
+            m = IPX_MOTIF_PRESENT | (d0 << 6) | (d1 << 4) | (a0 << 2) | a1;
+            if (non) {
+                m |= IPX_MOTIF_NONACGT;
+            } else {
+                if (canon4(d0, d1, a0, a1)) m |= IPX_MOTIF_CANON_P;
+                // reverse complement of "d0d1/a0a1" is  ~a1 ~a0 / ~d1 ~d0
+                if (canon4(3 - a1, 3 - a0, 3 - d1, 3 - d0)) m |= IPX_MOTIF_CANON_RC;
+            }
+        }
+    }
+    jmotif[j] = m;
+}
+
+// does a record with read strand s create the junction?  
+__device__ __forceinline__ bool record_passes(uint32_t strand, uint32_t motif, int32_t sj_filter) {
+    if (!(motif & IPX_MOTIF_PRESENT)) return true;          // empty splice_sites pass any filter
+    if (sj_filter != IPX_SJ_CANON) return true;
+    const bool cp = motif & IPX_MOTIF_CANON_P, crc = motif & IPX_MOTIF_CANON_RC;
+    if (strand == '-') return crc;
+    if (strand == '.') return cp || crc;
+    return cp;
+}
+
+// ---- wave-segmented reductions -------------------------------------------------
+// seg ids are non-decreasing over the lanes; the result is valid at head lanes.
+__device__ __forceinline__ uint32_t seg_last_lane(uint64_t heads, uint32_t lane) {
+    const uint64_t above = (lane == 63) ? 0ull : (heads & (~0ull << (lane + 1)));
+    return above ? (uint32_t)(__ffsll((unsigned long long)above) - 2) : 63u;
+}
+
+template <typename T, typename Op>
+__device__ __forceinline__ T seg_reduce(T v, uint32_t lane, uint32_t last, Op op) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const T o = __shfl_down(v, d);
+        if (lane + d <= last) v = op(v, o);
+    }
+    return v;
+}
+
+struct MinU64 { __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };
+struct MinU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; } };
+struct MaxU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
+struct AddU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+
+// phase A: first[j] = min order over all records; creator[j] = min over passing
+__global__ __launch_bounds__(256) void k_phase_a(const uint4 *a, const uint4 *b,
+                                                 const uint32_t *pass_skip, uint32_t n_digits,
+                                                 uint64_t n, const uint4 *__restrict__ pays,
+                                                 const uint32_t *__restrict__ chunk_j,
+                                                 const uint32_t *__restrict__ jmotif,
+                                                 int32_t sj_filter,
+                                                 unsigned long long *__restrict__ first,
+                                                 unsigned long long *__restrict__ creator) {
+    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lane_le = ~0ull >> (63 - lane);
+    const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t base = chunk * CHUNK;
+    if (base >= n) return;
+    uint32_t nj = chunk_j[chunk];
+#pragma unroll 1
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
+        const uint64_t mj = __ballot(h.head_j);
+        const uint64_t ok_mask = __ballot(h.ok);
+        if (!ok_mask) break;
+        const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
+        nj += (uint32_t)__popcll(mj);
+        unsigned long long ord = NONE64, ordp = NONE64;
+        if (h.ok) {
+            const uint4 p = pays[h.it.w];
+            ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
+            ordp = record_passes(IPX_ORD_STRAND(ord), jmotif[jid], sj_filter) ? ord : NONE64;
+        }
+        // lanes past the end form their own segment; lane 0 always starts one
+        const uint64_t heads = mj | 1ull | (~ok_mask & (ok_mask << 1));
+        const uint32_t last = seg_last_lane(heads, lane);
+        const unsigned long long m_all = seg_reduce(ord, lane, last, MinU64());
+        const unsigned long long m_pass = seg_reduce(ordp, lane, last, MinU64());
+        if (h.ok && ((heads >> lane) & 1ull)) {
+            atomicMin(&first[jid], m_all);
+            if (m_pass != NONE64) atomicMin(&creator[jid], m_pass);
+        }
+    }
+}
+
+// phase B: tallies over the counted records
+__global__ __launch_bounds__(256) void k_phase_b(const uint4 *a, const uint4 *b,
+                                                 const uint32_t *pass_skip, uint32_t n_digits,
+                                                 uint64_t n, const uint4 *__restrict__ pays,
+                                                 const uint32_t *__restrict__ chunk_j,
+                                                 const uint32_t *__restrict__ chunk_b,
+                                                 const unsigned long long *__restrict__ creator,
+                                                 unsigned long long *__restrict__ counts,   // 3 per junction
+                                                 uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
+                                                 uint32_t *__restrict__ bin_count,
+                                                 Counters *counters) {
+    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lane_le = ~0ull >> (63 - lane);
+    const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t base = chunk * CHUNK;
+    if (base >= n) return;
+    uint32_t nj = chunk_j[chunk], nb = chunk_b[chunk];
+#pragma unroll 1
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
+        const uint64_t mj = __ballot(h.head_j), mb = __ballot(h.head_b);
+        const uint64_t ok_mask = __ballot(h.ok);
+        if (!ok_mask) break;
+        const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
+        const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
+        nj += (uint32_t)__popcll(mj);
+        nb += (uint32_t)__popcll(mb);
+        uint32_t counted = 0, cpk = 0, lo = 0xffffffffu, hi = 0;
+        unsigned long long poison = NONE64;
+        if (h.ok) {
+            const uint4 p = pays[h.it.w];
+            const unsigned long long ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
+            const unsigned long long cr = creator[jid];
+            if (cr != NONE64 && IPX_ORD_SEQ(ord) >= IPX_ORD_SEQ(cr)) {
+                counted = 1;
+                const uint32_t cat = IPX_ORD_CAT(ord);
+                if (cat == 3) {     // get_read_category throws, junctions_extractor.cc:73-74
+                    poison = (ord & ~0x3ffull) | (IPX_ERRK_CATEGORY << 8);
+                } else {
+                    cpk = 1u << (cat * 8);
+                }
+                lo = p.z;
+                hi = p.w;
+            }
+        }
+        const uint64_t tail = ~ok_mask & (ok_mask << 1);
+        const uint64_t heads_j = mj | 1ull | tail, heads_b = mb | 1ull | tail;
+        const uint32_t last_j = seg_last_lane(heads_j, lane), last_b = seg_last_lane(heads_b, lane);
+        const uint32_t s_cpk = seg_reduce(cpk, lane, last_j, AddU32());
+        const uint32_t s_lo = seg_reduce(lo, lane, last_j, MinU32());
+        const uint32_t s_hi = seg_reduce(hi, lane, last_j, MaxU32());
+        const uint32_t s_bin = seg_reduce(counted, lane, last_b, AddU32());
+        if (h.ok && ((heads_j >> lane) & 1ull) && (s_cpk | (s_lo != 0xffffffffu))) {
+            const uint32_t c0 = s_cpk & 0xffu, c1 = (s_cpk >> 8) & 0xffu, c2 = (s_cpk >> 16) & 0xffu;
+            if (c0) atomicAdd(&counts[(uint64_t)jid * 3 + 0], (unsigned long long)c0);
+            if (c1) atomicAdd(&counts[(uint64_t)jid * 3 + 1], (unsigned long long)c1);
+            if (c2) atomicAdd(&counts[(uint64_t)jid * 3 + 2], (unsigned long long)c2);
+            atomicMin(&amin[jid], s_lo);
+            atomicMax(&amax[jid], s_hi);
+        }
+        if (h.ok && ((heads_b >> lane) & 1ull) && s_bin) atomicAdd(&bin_count[bid], s_bin);
+        // rare: a counted record whose category lookup throws
+        unsigned long long e = poison;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(e, d);
+            e = o < e ? o : e;
+        }
+        if (lane == 0 && e != NONE64) atomicMin(&counters->err_word, e);
+    }
+}
+
+// per junction: validity, final strand, genome errors; per-junction bin counting is in k_bins
+__global__ __launch_bounds__(256) void k_finish_junctions(uint32_t n_j,
+                                                          const unsigned long long *__restrict__ first,
+                                                          const unsigned long long *__restrict__ creator,
+                                                          const uint32_t *__restrict__ jmotif,
+                                                          uint32_t *__restrict__ jvalid,
+                                                          uint8_t *__restrict__ jstrand,
+                                                          Counters *counters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_j) return;
+    const uint32_t m = jmotif[j];
+    if (m & 0x300u) {
+        // the first record of the key is the one whose fetch throws
+        const unsigned long long f = first[j];
+        atomicMin(&counters->err_word,
+                  (f & ~0x3ffull) | (IPX_ERRK_GENOME << 8) | ((m & 0x200u) ? 1u : 0u));
+    }
+    const unsigned long long cr = creator[j];
+    const bool valid = (cr != NONE64) && !(m & 0x300u);
+    jvalid[j] = valid ? 1u : 0u;
+    uint32_t s = '.';
+    if (valid) {
+        s = IPX_ORD_STRAND(cr);
+        if ((m & IPX_MOTIF_PRESENT) && s == '.') {          // correct_strand :431-444
+            if (m & IPX_MOTIF_CANON_P) s = '+';
+            else if (m & IPX_MOTIF_CANON_RC) s = '-';
+        }
+    }
+    jstrand[j] = (uint8_t)s;
+}
+
+// non-empty bins: flag for compaction, and count them per junction
+__global__ __launch_bounds__(256) void k_bins(uint32_t n_b, const uint32_t *__restrict__ bin_count,
+                                              const uint32_t *__restrict__ bin_j,
+                                              uint32_t *__restrict__ bin_flag,
+                                              uint32_t *__restrict__ jnb) {
+    const uint32_t bidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bidx >= n_b) return;
+    const uint32_t nz = bin_count[bidx] ? 1u : 0u;
+    bin_flag[bidx] = nz;
+    if (nz) atomicAdd(&jnb[bin_j[bidx]], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_emit_bins(uint32_t n_b, const uint32_t *__restrict__ bin_count,
+                                                   const uint32_t *__restrict__ bin_off,
+                                                   const uint32_t *__restrict__ bin_pos,
+                                                   uint16_t *__restrict__ hist_value,
+                                                   uint32_t *__restrict__ hist_count) {
+    const uint32_t bidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bidx >= n_b) return;
+    const uint32_t c = bin_count[bidx];
+    if (c) {
+        const uint32_t p = bin_pos[bidx];
+        hist_value[p] = (uint16_t)bin_off[bidx];
+        hist_count[p] = c;
+    }
+}
+
+struct TableDev {
+    uint32_t *target, *intron_start, *intron_end, *anchor_start, *anchor_end;
+    uint8_t *strand;
+    uint16_t *motif;
+    uint64_t *read_counts, *creator_index, *hist_begin;
+    uint32_t *ijunc;
+};
+
+__global__ __launch_bounds__(256) void k_emit_junctions(
+    uint32_t n_j, const uint32_t *__restrict__ jvalid, const uint32_t *__restrict__ jpos,
+    const uint32_t *__restrict__ jrank, const uint32_t *__restrict__ jstart,
+    const uint32_t *__restrict__ jend, const uint32_t *__restrict__ amin,
+    const uint32_t *__restrict__ amax, const uint8_t *__restrict__ jstrand,
+    const uint32_t *__restrict__ jmotif, const unsigned long long *__restrict__ counts,
+    const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jnb_scan,
+    const uint32_t *__restrict__ tid_of_rank, const uint32_t *n_valid_total,
+    const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
+    if (j >= n_j || !jvalid[j]) return;
+    const uint32_t o = jpos[j];
+    out.target[o] = tid_of_rank[jrank[j]];
+    out.intron_start[o] = jstart[j];
+    out.intron_end[o] = jend[j];
+    out.anchor_start[o] = amin[j];
+    out.anchor_end[o] = amax[j];
+    out.strand[o] = jstrand[j];
+    out.motif[o] = (uint16_t)(jmotif[j] & 0xf0ffu);
+    out.read_counts[(uint64_t)o * 3 + 0] = counts[(uint64_t)j * 3 + 0];
+    out.read_counts[(uint64_t)o * 3 + 1] = counts[(uint64_t)j * 3 + 1];
+    out.read_counts[(uint64_t)o * 3 + 2] = counts[(uint64_t)j * 3 + 2];
+    const unsigned long long cr = creator[j];
+    out.creator_index[o] = IPX_ORD_READ(cr);
+    out.hist_begin[o] = jnb_scan[j];
+    // creation order = (read_index, ordinal): sort key for the ijunc ranks
+    const unsigned long long seq = IPX_ORD_SEQ(cr);
+    rank_items[o] = make_uint4((uint32_t)seq, (uint32_t)(seq >> 32), 0u, o);
+}
+
+__global__ __launch_bounds__(256) void k_emit_ijunc(uint32_t n, const uint4 *a, const uint4 *b,
+                                                    const uint32_t *pass_skip, uint32_t n_digits,
+                                                    uint32_t *__restrict__ ijunc) {
+    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ijunc[items[i].w] = i;
+}
+
+// after a genome error: which key did the failing record belong to?
+__global__ __launch_bounds__(256) void k_find_genome_error(uint32_t n_j,
+                                                           const unsigned long long *__restrict__ first,
+                                                           const uint32_t *__restrict__ jmotif,
+                                                           const uint32_t *__restrict__ jrank,
+                                                           const uint32_t *__restrict__ jstart,
+                                                           const uint32_t *__restrict__ jend,
+                                                           unsigned long long err_seq, uint32_t *detail4) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_j) return;
+    if ((jmotif[j] & 0x300u) && IPX_ORD_SEQ(first[j]) == err_seq) {
+        detail4[0] = jrank[j]; detail4[1] = jstart[j]; detail4[2] = jend[j]; detail4[3] = 1;
+    }
+}
+
+}  // namespace
+
+// ---- launch wrappers (host side of this translation unit) ----------------------
+#include "ipx_reduce.h"
+
+static inline dim3 grid1d(uint64_t n, uint32_t per_block) { return dim3((uint32_t)ipx_div_up(n ? n : 1, per_block)); }
+
+uint64_t ipx_reduce_chunks(uint64_t n) { return ipx_div_up(n, CHUNK); }
+
+hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b) {
+    const uint64_t chunks = ipx_div_up(si.n, CHUNK);
+    hipLaunchKernelGGL(k_count_heads, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
+                       si.n_digits, si.n, chunk_j, chunk_b);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const KeyLayout &kl,
+                             const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
+                             int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters) {
+    const uint64_t chunks = ipx_div_up(si.n, CHUNK);
+    const uint32_t J = rb.n_j, B = rb.n_b;
+    hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
+                       si.n_digits, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
+                       rb.bin_j, rb.bin_off);
+    hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
+                       rb.jstart, rb.jend, rb.jmotif);
+    hipError_t e;
+    if ((e = hipMemsetAsync(rb.first, 0xff, sizeof(uint64_t) * J, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.creator, 0xff, sizeof(uint64_t) * J, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.amin, 0xff, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.amax, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.counts, 0, sizeof(uint64_t) * 3 * J, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.jnb, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.bin_count, 0, sizeof(uint32_t) * B, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_phase_a, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
+                       si.n_digits, si.n, pays, rb.chunk_j, rb.jmotif, sj_filter, rb.first, rb.creator);
+    hipLaunchKernelGGL(k_phase_b, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
+                       si.n_digits, si.n, pays, rb.chunk_j, rb.chunk_b, rb.creator, rb.counts, rb.amin,
+                       rb.amax, rb.bin_count, counters);
+    hipLaunchKernelGGL(k_finish_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.first, rb.creator,
+                       rb.jmotif, rb.jvalid, rb.jstrand, counters);
+    hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_j, rb.bin_flag,
+                       rb.jnb);
+    // compaction offsets: junctions, bins, bins per junction
+    if ((e = ipx_launch_scan_u32(s, rb.jvalid, rb.jpos, J, rb.scan_sums, rb.totals + 0)) != hipSuccess) return e;
+    if ((e = ipx_launch_scan_u32(s, rb.bin_flag, rb.bin_pos, B, rb.scan_sums, rb.totals + 1)) != hipSuccess) return e;
+    if ((e = ipx_launch_scan_u32(s, rb.jnb, rb.jnb, J, rb.scan_sums, nullptr)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
+                       rb.bin_pos, rb.out_hist_value, rb.out_hist_count);
+    TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
+                rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
+                rb.out_creator_index, rb.out_hist_begin, rb.out_ijunc};
+    hipLaunchKernelGGL(k_emit_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
+                       rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
+                       rb.jnb, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *a, const uint4 *b,
+                                 const uint32_t *pass_skip, uint32_t n_digits, uint32_t *ijunc) {
+    if (n_valid == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_emit_ijunc, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, a, b, pass_skip,
+                       n_digits, ijunc);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_find_genome_error(hipStream_t s, uint32_t n_j, const unsigned long long *first,
+                                        const uint32_t *jmotif, const uint32_t *jrank,
+                                        const uint32_t *jstart, const uint32_t *jend,
+                                        unsigned long long err_seq, uint32_t *detail4) {
+    hipLaunchKernelGGL(k_find_genome_error, grid1d(n_j, 256), dim3(256), 0, s, n_j, first, jmotif, jrank,
+                       jstart, jend, err_seq, detail4);
+    return hipGetLastError();
+}

@@ -1,0 +1,166 @@
+"""Python host-side mirror of the reference's JunctionsExtractor for SoA batches.
+
+This is harness plumbing over the C ABI (include/ipx.h) used by the tests and by
+bench.py; the product host is the C++ code in intronprospector_amd/host.  The
+method names follow src/junctions_extractor.hh:176-255 of the reference where
+one exists (clear, get_junctions); errors raised by the input are re-raised with
+the reference's message text.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class IpxError(RuntimeError):
+    def __init__(self, status, err):
+        self.status = status
+        self.kind = err.kind
+        self.read_index = err.read_index
+        self.target = err.target
+        self.detail = err.detail.decode(errors="replace")
+        super().__init__(self.detail or ("ipx status %d" % status))
+
+
+_NP = {
+    "target": np.uint32, "intron_start": np.uint32, "intron_end": np.uint32, "anchor_start": np.uint32,
+    "anchor_end": np.uint32, "strand": np.uint8, "motif": np.uint16, "creator_index": np.uint64,
+    "ijunc": np.uint32,
+}
+
+
+def _view(ptr, n, dtype):
+    if not n:
+        return np.zeros(0, dtype)
+    dt = np.dtype(dtype)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+
+class JunctionsExtractor:
+    def __init__(self, min_anchor_length=8, max_anchor_indel_size=0, min_intron_length=70,
+                 max_intron_length=500000, junction_filter=L.IPX_SJ_NULL, strandness=L.IPX_UNSTRANDED,
+                 excludes=0, skip_missing_targets=False, scope=L.IPX_SCOPE_TARGET, device=0,
+                 targets=(), target_lengths=None, genome=None):
+        self.lib = L.load()
+        p = L.Params(min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length,
+                     junction_filter, strandness, excludes, scope, int(bool(skip_missing_targets)), device)
+        h = C.c_void_p()
+        rc = self.lib.ipx_create(C.byref(p), C.byref(h))
+        if rc == L.IPX_ENODEVICE:
+            raise RuntimeError("intronprospector_amd: no gfx950 device available (ipx_create -> IPX_ENODEVICE); "
+                               "there is no CPU fallback")
+        if rc:
+            raise RuntimeError("ipx_create failed with status %d" % rc)
+        self.h = h
+        self.next_read_index = 0
+        self._keep = []
+        if len(targets):
+            self.set_targets(targets, target_lengths)
+        if genome is not None:
+            self.set_genome(*genome)
+
+    # -- configuration -----------------------------------------------------
+    def _check(self, rc):
+        if rc:
+            e = L.Error()
+            self.lib.ipx_last_error(self.h, C.byref(e))
+            raise IpxError(rc, e)
+
+    def set_targets(self, names, lengths=None):
+        arr = (C.c_char_p * len(names))(*[n.encode() if isinstance(n, str) else n for n in names])
+        lens = None
+        if lengths is not None:
+            lens = (C.c_int64 * len(names))(*[int(x) for x in lengths])
+        self._check(self.lib.ipx_set_targets(self.h, len(names), arr, lens))
+
+    def set_genome(self, names, seqs_2bit):
+        """names, [(twobit bytes, mask bytes, length), ...] as produced by synth.pack_2bit."""
+        n = len(names)
+        arr = (C.c_char_p * n)(*[s.encode() for s in names])
+        lens = (C.c_int64 * n)(*[int(t[2]) for t in seqs_2bit])
+        two = (C.c_void_p * n)(*[t[0].ctypes.data for t in seqs_2bit])
+        msk = (C.c_void_p * n)(*[t[1].ctypes.data for t in seqs_2bit])
+        self._check(self.lib.ipx_set_genome_2bit(self.h, n, arr, lens, two, msk))
+
+    def reserve(self, n_alignments, n_cigar_words, n_records):
+        self._check(self.lib.ipx_reserve(self.h, n_alignments, n_cigar_words, n_records))
+
+    # -- data --------------------------------------------------------------
+    def push(self, batch, base_read_index=None):
+        """batch: dict of numpy arrays (host) with the keys of synth._flatten."""
+        n = len(batch["tid"])
+        if base_read_index is None:
+            base_read_index = self.next_read_index
+        arrs = {k: np.ascontiguousarray(batch[k], dt) for k, dt in (
+            ("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("xs", np.uint8), ("nh", np.uint8),
+            ("cigar_off", np.uint32), ("n_cigar", np.uint32), ("cigar", np.uint32))}
+        b = L.Batch(n, len(arrs["cigar"]), base_read_index,
+                    *[arrs[k].ctypes.data for k in ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")],
+                    L.IPX_MEM_HOST)
+        self._check(self.lib.ipx_push_batch(self.h, C.byref(b)))
+        self.next_read_index = base_read_index + n
+
+    def push_device(self, n, n_words, ptrs, base_read_index=None):
+        """ptrs: device addresses in the order tid,pos,flag,xs,nh,cigar_off,n_cigar,cigar."""
+        if base_read_index is None:
+            base_read_index = self.next_read_index
+        b = L.Batch(n, n_words, base_read_index, *ptrs, L.IPX_MEM_DEVICE)
+        self._check(self.lib.ipx_push_batch(self.h, C.byref(b)))
+        self.next_read_index = base_read_index + n
+
+    def finalize_raw(self, memory=L.IPX_MEM_HOST):
+        t = L.Table()
+        rc = self.lib.ipx_finalize(self.h, memory, C.byref(t))
+        return rc, t
+
+    def get_junctions(self):
+        """The table as numpy arrays, rows in std::map order."""
+        rc, t = self.finalize_raw(L.IPX_MEM_HOST)
+        if rc and rc != L.IPX_EDATA:
+            self._check(rc)
+        n = t.n_junctions
+        out = {k: _view(getattr(t, k), n, dt) for k, dt in _NP.items()}
+        out["counts"] = _view(t.read_counts, 3 * n, np.uint64).reshape(n, 3)
+        out["hist_begin"] = _view(t.hist_begin, n + 1, np.uint64) if n else np.zeros(1, np.uint64)
+        out["hist_value"] = _view(t.hist_value, t.n_hist, np.uint16)
+        out["hist_count"] = _view(t.hist_count, t.n_hist, np.uint32)
+        out["n_records"] = t.n_records
+        out["n_alignments"] = t.n_alignments
+        if rc == L.IPX_EDATA:
+            e = L.Error()
+            self.lib.ipx_last_error(self.h, C.byref(e))
+            out["error"] = IpxError(rc, e)
+        return out
+
+    def timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self.lib.ipx_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def clear(self):
+        self._check(self.lib.ipx_clear(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ipx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def expand_histogram(table):
+    """CSR histogram -> the sorted uint16 offset multiset, concatenated per junction
+    (what Junction::read_offsets holds after calculate_confidence sorted it)."""
+    return np.repeat(table["hist_value"], table["hist_count"].astype(np.int64))
+
+
+def offsets_per_junction(table):
+    hb = table["hist_begin"].astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(table["hist_count"].astype(np.int64))])
+    return csum[hb[1:]] - csum[hb[:-1]]

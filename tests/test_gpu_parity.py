@@ -1,0 +1,248 @@
+"""GPU parity: the HIP path through the C ABI (libipx.so) against the CPU oracle,
+bit for bit, on seeded synthetic batches and on the reference's own inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.oracle_binding import Oracle, OracleError
+
+pytestmark = pytest.mark.gpu
+
+
+def _extractor(**kw):
+    import intronprospector_amd as ipa
+    return ipa.JunctionsExtractor(**kw)
+
+
+def _run_both(batch, names, params=None, genome=None, fasta=None, scope=0, n_push=1):
+    """-> (device table, oracle table). params: dict with oracle-style keys."""
+    from intronprospector_amd import synth
+    params = dict(params or {})
+    gen2 = None
+    if genome is not None:
+        gen2 = (genome.names, [(t, m, len(s)) for (t, m), s in zip(genome.twobit(), genome.seqs)])
+    ex = _extractor(targets=names, scope=scope, genome=gen2, **params)
+    n = len(batch["tid"])
+    cuts = np.linspace(0, n, n_push + 1).astype(int)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ex.push(synth.slice_batch(batch, int(a), int(b)))
+    dev = ex.get_junctions()
+    ex.close()
+    ora = Oracle(targets=names, genome_fasta=fasta, **params)
+    err = None
+    try:
+        ora.process(batch)
+    except OracleError as e:
+        err = e
+    tab = ora.table()
+    ora.close()
+    return dev, tab, err
+
+
+def _fetcher(genome):
+    def fetch(tid, start, end):
+        s = genome.seqs[tid]
+        return bytes([s[start], s[start + 1], s[end - 2], s[end - 1]])
+    return fetch
+
+
+@pytest.mark.parametrize("params", [
+    {},
+    {"excludes": 1},
+    {"strandness": 1},
+    {"strandness": 2, "min_anchor_length": 1, "min_intron_length": 1, "max_intron_length": 4000000},
+    {"min_anchor_length": 20, "min_intron_length": 200, "max_intron_length": 50000},
+])
+def test_short_reads_match_oracle(params):
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(120_000, seed=11, n_targets=5, target_len=6_000_000, n_sites=4000)
+    dev, ora, err = _run_both(batch, names, params)
+    assert err is None and "error" not in dev
+    assert len(ora["intron_start"]) > 1000
+    helpers.compare_tables(dev, ora)
+
+
+def test_short_reads_multiple_pushes_equal_single():
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(60_000, seed=12, n_targets=3, target_len=4_000_000, n_sites=1500)
+    dev, ora, err = _run_both(batch, names, {}, n_push=7)
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
+@pytest.mark.parametrize("flt", [0, 1, 2])
+def test_genome_filter_strand_motif(tmp_path, flt):
+    """config G: device 2-bit genome, canonical filter, fail-then-pass ordering."""
+    from intronprospector_amd import synth
+    batch, names, gen = synth.short_reads(80_000, seed=13, n_targets=3, target_len=3_000_000, n_sites=1200, genome=True)
+    fa = str(tmp_path / "g.fa")
+    gen.write_fasta(fa)
+    dev, ora, err = _run_both(batch, names, {"junction_filter": flt}, genome=gen, fasta=fa)
+    assert err is None and "error" not in dev
+    helpers.compare_tables(dev, ora, _fetcher(gen))
+    if flt == 2:
+        # the filter must actually have dropped something and flipped some strands
+        assert (ora["strand"] == ord("-")).any() and (ora["strand"] == ord("+")).any()
+
+
+def test_genome_global_scope_name_order(tmp_path):
+    """--unsorted / multi-input semantics: one table keyed by chromosome NAME."""
+    from intronprospector_amd import synth
+    batch, names, gen = synth.short_reads(40_000, seed=14, n_targets=12, target_len=2_700_000, n_sites=900, genome=True)
+    # chr1, chr10, chr11, chr12, chr2 ...: name order differs from tid order
+    fa = str(tmp_path / "g.fa")
+    gen.write_fasta(fa)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(batch["tid"]))          # unsorted input
+    shuffled = synth.concat_batches([synth.slice_batch(batch, int(i), int(i) + 1) for i in perm[:6000]])
+    dev, ora, err = _run_both(shuffled, names, {"junction_filter": 2}, genome=gen, fasta=fa, scope=1)
+    assert err is None
+    helpers.compare_tables(dev, ora, _fetcher(gen))
+    # rows come back in std::map order: (name, start, end)
+    nm = np.array(names)[dev["target"]]
+    key = list(zip(nm.tolist(), dev["intron_start"].tolist(), dev["intron_end"].tolist()))
+    assert key == sorted(key)
+
+
+@pytest.mark.parametrize("max_indel", [0, 3, 36])
+def test_long_reads_match_oracle(max_indel):
+    from intronprospector_amd import synth
+    batch, names, _ = synth.long_reads(1500, seed=15, n_targets=3, target_len=9_000_000, n_transcripts=60)
+    dev, ora, err = _run_both(batch, names, {"max_anchor_indel_size": max_indel})
+    assert err is None
+    if max_indel:
+        assert len(ora["intron_start"]) > 100
+    helpers.compare_tables(dev, ora)
+
+
+GOLDEN_INPUTS = ["test_basic.sam", "test_multi.sam", "ont.sam", "ont-skip-targets.sam", "fake10.star.sam",
+                 "fake10.hisat2.sam", "sort-bug.sam"]
+
+
+@pytest.mark.parametrize("sam", GOLDEN_INPUTS)
+@pytest.mark.parametrize("indels", [0, 36])
+def test_reference_inputs_match_oracle(golden, sam, indels):
+    names, batch, _ = helpers.parse_sam(os.path.join(golden, "input", sam))
+    dev, ora, err = _run_both(batch, names, {"max_anchor_indel_size": indels})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
+def test_reference_fake10_with_genome(golden):
+    from intronprospector_amd import synth
+    fa = os.path.join(golden, "input", "fake10_scramble_genome.fa")
+    seq = np.frombuffer(b"".join(l.strip() for l in open(fa, "rb").readlines()[1:]), np.uint8)
+    gen = synth.Genome(["fake10"], [seq])
+    names, batch, _ = helpers.parse_sam(os.path.join(golden, "input", "fake10.star.sam"))
+    for flt in (1, 2):
+        dev, ora, err = _run_both(batch, names, {"junction_filter": flt}, genome=gen, fasta=fa)
+        assert err is None
+        helpers.compare_tables(dev, ora, _fetcher(gen))
+
+
+def test_known_answer_fail_then_pass(golden):
+    """SURVEY.md 8a-7 recorded reference output, through the device path."""
+    from intronprospector_amd import synth
+    fa = os.path.join(golden, "input", "fake10_genome.fa")
+    seq = np.frombuffer(b"".join(l.strip() for l in open(fa, "rb").readlines()[1:]), np.uint8)
+    gen = synth.Genome(["fake10"], [seq])
+    names, batch, _ = helpers.parse_sam(os.path.join(golden, "known", "fail_then_pass.sam"))
+    dev, ora, _ = _run_both(batch, names, {"junction_filter": 2}, genome=gen, fasta=fa)
+    assert dev["strand"].tolist() == [ord("+")] and dev["counts"].tolist() == [[2, 0, 0]]
+    assert (dev["intron_start"][0] - dev["anchor_start"][0], dev["anchor_end"][0] - dev["intron_end"][0]) == (68, 43)
+    dev, ora, _ = _run_both(batch, names, {"junction_filter": 1}, genome=gen, fasta=fa)
+    assert dev["strand"].tolist() == [ord("-")] and dev["counts"].tolist() == [[3, 0, 0]]
+    assert helpers.motif_string(int(dev["strand"][0]), int(dev["motif"][0])) == b"ct/ac"
+
+
+def _one_read(cigar_words, flag=0, pos=1000, tid=0, nh=1):
+    return {"tid": np.array([tid], np.int32), "pos": np.array([pos], np.int32),
+            "flag": np.array([flag], np.uint16), "xs": np.zeros(1, np.uint8), "nh": np.array([nh], np.uint8),
+            "cigar_off": np.zeros(1, np.uint32), "n_cigar": np.array([len(cigar_words)], np.uint32),
+            "cigar": np.array(cigar_words, np.uint32)}
+
+
+def _cig(s):
+    out, num = [], ""
+    for ch in s:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((int(num) << 4) | "MIDNSHP=XB".index(ch))
+            num = ""
+    return out
+
+
+def test_stale_indel_counter_quirk():
+    """SURVEY.md 8a-1 recorded reference outputs."""
+    from intronprospector_amd import synth
+    p = {"max_anchor_indel_size": 3, "min_intron_length": 10}
+    for cig, exp in (("20M5D9M100N20M", []), ("9M100N20M", [(1009, 1109, 9, 20)]),
+                     ("10M50N5M80N10M1D2I30M200N10M", [(1186, 1386, 41, 10)])):
+        dev, ora, _ = _run_both(_one_read(_cig(cig)), ["chr1"], p)
+        got = [(int(s), int(e), int(s - a), int(b - e)) for s, e, a, b in
+               zip(dev["intron_start"], dev["intron_end"], dev["anchor_start"], dev["anchor_end"])]
+        assert got == exp, cig
+        helpers.compare_tables(dev, ora)
+
+
+def test_errors_earliest_in_input_order():
+    from intronprospector_amd import synth
+    import intronprospector_amd as ipa
+    batch, names, _ = synth.short_reads(5000, seed=16, n_targets=2, target_len=3_000_000, n_sites=100)
+    # plant: a padding op (P) in read 3000 and a B op in read 1200 -> the B must be reported
+    bad = synth.concat_batches([
+        synth.slice_batch(batch, 0, 1200), _one_read(_cig("10M100N10M5B")),
+        synth.slice_batch(batch, 1200, 3000), _one_read(_cig("10M5P100N10M")),
+        synth.slice_batch(batch, 3000, 5000)])
+    dev, ora, err = _run_both(bad, names, {})
+    assert err is not None and err.index == 1200 and err.msg == "Unknown cigar operation 'B'"
+    e = dev["error"]
+    assert e.kind == 1 and e.read_index == 1200 and e.detail == "Unknown cigar operation 'B'"
+    # FUNMAP read with a spliced CIGAR reaches get_read_category -> logic_error
+    bad = synth.concat_batches([synth.slice_batch(batch, 0, 10), _one_read(_cig("30M100N30M"), flag=4)])
+    dev, ora, err = _run_both(bad, names, {})
+    assert err is not None and err.index == 10
+    assert dev["error"].kind == 2 and dev["error"].read_index == 10
+    assert dev["error"].detail == err.msg
+
+
+def test_genome_fetch_errors(tmp_path):
+    from intronprospector_amd import synth
+    gen = synth.Genome(["chr1", "chr2"], [np.frombuffer(b"ACGT" * 500, np.uint8).copy(), np.frombuffer(b"ACGT" * 500, np.uint8).copy()])
+    fa = str(tmp_path / "g.fa")
+    gen.write_fasta(fa)
+    # intron running past the end of the 2000-base sequence
+    rd = _one_read(_cig("20M1950N20M"), pos=100)
+    dev, ora, err = _run_both(rd, ["chr1", "chr2"], {"junction_filter": 1}, genome=gen, fasta=fa)
+    assert err is not None and dev["error"].kind == 4
+    assert dev["error"].detail == err.msg
+    # chromosome not in the genome
+    rd = _one_read(_cig("20M100N20M"), pos=100, tid=2)
+    dev, ora, err = _run_both(rd, ["chr1", "chr2", "chrX"], {"junction_filter": 1}, genome=gen, fasta=fa)
+    assert err is not None and dev["error"].kind == 3
+    assert dev["error"].detail == err.msg
+    # ... tolerated with skip_missing_targets: junction kept with empty motif
+    dev, ora, err = _run_both(rd, ["chr1", "chr2", "chrX"], {"junction_filter": 2, "skip_missing_targets": 1}, genome=gen, fasta=fa)
+    assert err is None and len(dev["intron_start"]) == 1 and dev["motif"][0] == 0
+
+
+def test_empty_and_degenerate_inputs():
+    from intronprospector_amd import synth
+    ex = _extractor(targets=["chr1"])
+    t = ex.get_junctions()
+    assert len(t["intron_start"]) == 0 and t["n_records"] == 0
+    # reads without junctions, unmapped reads, single-op CIGARs
+    b = synth.concat_batches([_one_read(_cig("100M")), _one_read(_cig("50M50S")), _one_read([], tid=-1),
+                              _one_read(_cig("10M100N10M"), flag=1024), _one_read(_cig("10M100N10M"), flag=512),
+                              _one_read(_cig("10M100N10M"), flag=256)])
+    ex.push(b)
+    t = ex.get_junctions()
+    assert len(t["intron_start"]) == 0 and t["n_alignments"] == 6
+    ex.clear()
+    ex.push(_one_read(_cig("10M100N10M")))
+    t = ex.get_junctions()
+    assert t["intron_start"].tolist() == [1010] and t["intron_end"].tolist() == [1110]
+    ex.close()

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the junction-extraction hot path on MI355X.
+
+A step is one pass of the path over one batch of synthetic alignments that is
+already resident in HBM: ipx_clear -> ipx_push_batch (CIGAR scan -> junction
+records) -> ipx_finalize (radix sort + segmented reduce -> junction table in
+HBM).  With N > 1 every rank holds its own contiguous shard of N x reads
+alignments (weak scaling) and the partial tables are combined over RCCL.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_workload(kind, reads, seed):
+    from intronprospector_amd import synth
+    if kind == "S":
+        return synth.short_reads(reads, seed=seed)
+    if kind == "L":
+        return synth.long_reads(reads, seed=seed)
+    raise SystemExit("unknown workload %r" % kind)
+
+
+# algorithmic bytes each kernel has to move per launch (DESIGN.md "Kernels"):
+# n alignments, w CIGAR words, r records
+KERNEL_BYTES = {
+    "k_scan": lambda n, w, r: 20 * n + 4 * w + 32 * r,     # SoA + CIGAR in, 32-byte records out
+    "k_hist": lambda n, w, r: 16 * r,                       # one read of the 16-byte sort items
+    "k_scatter": lambda n, w, r: 32 * r,                    # items in, items out
+    "k_count_heads": lambda n, w, r: 16 * r,
+    "k_write_heads": lambda n, w, r: 16 * r,
+    "k_phase_a": lambda n, w, r: 32 * r,                    # item + payload of every record
+    "k_phase_b": lambda n, w, r: 32 * r,
+}
+
+
+def cpu_baseline(batch, names, kind, budget_reads):
+    """The oracle (a scalar port of the reference, oracle/) timed on this host over
+    a bounded prefix of the same batch.  Reported next to the GPU number only."""
+    from intronprospector_amd import synth
+    from tests.oracle_binding import Oracle
+    n = min(budget_reads, len(batch["tid"]))
+    sample = synth.slice_batch(batch, 0, n)
+    params = {"max_anchor_indel_size": 36} if kind == "L" else {}
+    ora = Oracle(targets=names, **params)
+    t0 = time.perf_counter()
+    ora.process(sample)
+    nj = ora.lib.ipxo_num_junctions(ora.h)
+    t1 = time.perf_counter()
+    ora.close()
+    return {"value": n / (t1 - t0), "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": "first %d alignments of the %s workload, oracle/libipxo.so (scalar C restatement), "
+                      "%d junctions, %.1f s" % (n, kind, nj, t1 - t0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="S", choices=["S", "L"])
+    ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10M for S, 200k for L)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    from intronprospector_amd import _lib as L
+
+    kind = args.workload
+    reads = args.reads or (10_000_000 if kind == "S" else 200_000)
+    seed = (synth.SEED_S if kind == "S" else synth.SEED_L) if world == 1 else synth.SEED_M0 + rank
+    t_gen = time.perf_counter()
+    batch, names, _ = make_workload(kind, reads, seed)
+    t_gen = time.perf_counter() - t_gen
+    n = len(batch["tid"])
+    n_words = len(batch["cigar"])
+
+    keys = ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")
+    dev_arrays = [torch.from_numpy(batch[k]).to(dev) for k in keys]
+    ptrs = [t.data_ptr() for t in dev_arrays]
+    torch.cuda.synchronize()
+
+    params = {"max_anchor_indel_size": 36} if kind == "L" else {}
+    ex = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
+    ex.reserve(0, 0, n_words // 2 + 1024)
+
+    merger = None
+    if world > 1:
+        from intronprospector_amd import distributed
+        merger = distributed.TableMerger(dev)
+
+    n_records = [0]
+
+    def step():
+        ex.clear()
+        ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
+        rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
+        if rc:
+            ex._check(rc)
+        n_records[0] = table.n_records
+        if merger is not None:
+            merger.merge(ex, table, rank, world)
+        return table
+
+    for _ in range(args.warmup):
+        table = step()
+    ex.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = ex.profile_read()
+    ex.profile(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    n_junctions = int(table.n_junctions)
+    r = int(n_records[0])
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed
+        c = n_words / n
+        j = r / n
+        b_alg = 20 + 4 * c + 64 * j                      # SURVEY.md 8(d), bytes per alignment
+        dev_ms = sum(v[1] for v in stats.values()) / args.steps
+        dom = max(stats.items(), key=lambda kv: kv[1][1]) if stats else None
+        roofline = None
+        if dom:
+            name, (launches, total_ms) = dom
+            avg_ms = total_ms / launches
+            kb = KERNEL_BYTES.get(name, lambda n_, w_, r_: 0)(n, n_words, r)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(kind, {}).get(name)
+                except Exception:
+                    traffic = None
+            roofline = {
+                "bound": "hbm", "kernel": name, "launches_per_step": launches / args.steps,
+                "avg_ms": avg_ms, "algorithmic_bytes_per_launch": kb,
+                "achieved": kb / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                # whole path: SURVEY 8(d) algorithmic bytes over ALL device time of a step
+                "pipeline": {"bytes_per_alignment": b_alg, "device_ms_per_step": dev_ms,
+                             "achieved": b_alg * n / (dev_ms * 1e-3) / 1e9 if dev_ms else None,
+                             "frac": b_alg * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dev_ms else None},
+                "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+            }
+        out = {
+            "metric": "alignments/sec junction extraction", "value": value, "unit": "alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32/u64 integer",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d synthetic %s per GPU, %.2f CIGAR ops and %.2f junction records per "
+                                   "alignment, %d junctions in the table" %
+                                   (kind, n, "100 bp short reads (1-2 N ops)" if kind == "S" else "ONT-style long reads",
+                                    c, j, n_junctions),
+                       "alignments_per_gpu": n, "cigar_words": n_words, "records": r, "junctions": n_junctions,
+                       "seed": seed, "generate_s": t_gen},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample or (4_000_000 if kind == "S" else 20_000)
+            out["cpu_baseline"] = cpu_baseline(batch, names, kind, sample)
+        print(json.dumps(out))
+    ex.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -227,6 +227,16 @@ int ipx_finalize_shard(ipx_handle *h, ipx_table *out_from_creator, ipx_table *ou
  * measured with HIP events on the handle's stream */
 int ipx_last_timing(const ipx_handle *h, float *push_ms, float *finalize_ms);
 
+/* Per-kernel device time, measured with HIP event pairs on the handle's stream
+ * around every launch while profiling is enabled (bench.py's roofline figures). */
+typedef struct ipx_kernel_stat {
+    char     name[32];
+    uint64_t launches;
+    double   total_ms;
+} ipx_kernel_stat;
+int ipx_profile(ipx_handle *h, int enable);     /* enable/disable, resets the sums */
+int ipx_profile_read(const ipx_handle *h, ipx_kernel_stat *out, uint32_t cap, uint32_t *n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ MOTIF_PRESENT, MOTIF_NONACGT, MOTIF_CANON_P, MOTIF_CANON_RC = 0x8000, 0x4000, 0x
 SYMBOLS = [
     "ipx_abi_version", "ipx_create", "ipx_destroy", "ipx_set_targets", "ipx_set_genome_2bit",
     "ipx_reserve", "ipx_push_batch", "ipx_finalize", "ipx_clear", "ipx_last_error",
-    "ipx_finalize_shard", "ipx_last_timing",
+    "ipx_finalize_shard", "ipx_last_timing", "ipx_profile", "ipx_profile_read",
 ]
 
 
@@ -64,6 +64,10 @@ class Error(C.Structure):
     ]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
 _lib = None
 
 
@@ -91,6 +95,8 @@ def load():
     lib.ipx_last_error.argtypes = [vp, C.POINTER(Error)]
     lib.ipx_finalize_shard.argtypes = [vp, C.POINTER(Table), C.POINTER(Table)]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.ipx_profile.argtypes = [vp, C.c_int]
+    lib.ipx_profile_read.argtypes = [vp, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]
     for name in SYMBOLS:
         getattr(lib, name)
     _lib = lib

@@ -37,8 +37,52 @@ struct Arena {
 
 }  // namespace
 
+// event-pair profiler: a timeline of marks on the handle's stream
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    std::vector<int> ids;          // id of mark k (interval k-1 -> k is charged to ids[k])
+    double total_ms[IPXK_COUNT] = {};
+    uint64_t launches[IPXK_COUNT] = {};
+    void mark(hipStream_t s, int id) {
+        if (ids.size() == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            pool.push_back(e);
+        }
+        if (hipEventRecord(pool[ids.size()], s) == hipSuccess) ids.push_back(id);
+    }
+    // call after the stream was synchronized
+    void collect() {
+        for (size_t k = 1; k < ids.size(); ++k) {
+            if (ids[k] == IPXK_BEGIN) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pool[k - 1], pool[k]) == hipSuccess) {
+                total_ms[ids[k]] += ms;
+                launches[ids[k]] += 1;
+            }
+        }
+        ids.clear();
+    }
+    void reset() {
+        ids.clear();
+        for (int i = 0; i < IPXK_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; }
+    }
+    ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+static thread_local Profiler *g_prof = nullptr;
+void ipx_prof_mark(hipStream_t s, int id) {
+    if (g_prof && g_prof->on) g_prof->mark(s, id);
+}
+struct ProfScope {
+    explicit ProfScope(Profiler *p) { g_prof = p; }
+    ~ProfScope() { g_prof = nullptr; }
+};
+
 struct ipx_handle {
     ipx_params params{};
+    Profiler prof;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // targets
@@ -396,13 +440,16 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     sp.n_targets = (uint32_t)h->names.size();
     sp.key = h->key;
 
+    ProfScope prof_scope(&h->prof);
     for (int attempt = 0; attempt < 2; ++attempt) {
+        ipx_prof_mark(h->stream, IPXK_BEGIN);
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
                                h->pays.as<uint4>(), h->rec_cap, h->counters.as<Counters>()));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
         if (c->n_records <= h->rec_cap) {
             h->seen_words += nw;
@@ -460,6 +507,8 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
     ReduceBuffers rb{};
     unsigned long long err_word = IPX_ERRW_NONE;
 
+    ProfScope prof_scope(&h->prof);
+    ipx_prof_mark(s, IPXK_BEGIN);
     HIPCHK(hipEventRecord(h->ev[2], s));
     if (R > 0) {
         // one workspace serves the sort (digit histograms) and, once the sort is done,
@@ -484,6 +533,8 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
         HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
         HIPCHK(hipMemcpyAsync(small, tot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        h->prof.collect();
+        ipx_prof_mark(s, IPXK_BEGIN);
         J = small[0];
         B = small[1];
 
@@ -536,6 +587,8 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
         HIPCHK(hipMemcpyAsync(small, rb.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(small + 4, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        h->prof.collect();
+        ipx_prof_mark(s, IPXK_BEGIN);
         n_valid = small[0];
         n_hist = small[1];
         err_word = ((const Counters *)(small + 4))->err_word;
@@ -624,6 +677,7 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
         }
     }
     (void)hipEventElapsedTime(&h->fin_ms, h->ev[2], h->ev[3]);
+    h->prof.collect();
     h->table = t;
     *out = t;
     if (err_word != IPX_ERRW_NONE) {
@@ -661,6 +715,35 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
         }
         return IPX_EDATA;
     }
+    return IPX_OK;
+}
+
+static const char *const kKernelNames[IPXK_COUNT] = {
+    "begin", "k_scan", "k_hist", "sort_hist_scan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
+    "k_write_heads", "k_motif", "memset", "k_phase_a", "k_phase_b", "k_finish_junctions", "k_bins",
+    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy"};
+
+int ipx_profile(ipx_handle *h, int enable) {
+    if (!h) return IPX_EINVAL;
+    h->prof.on = enable != 0;
+    h->prof.reset();
+    return IPX_OK;
+}
+
+int ipx_profile_read(const ipx_handle *h, ipx_kernel_stat *out, uint32_t cap, uint32_t *n) {
+    if (!h || !n) return IPX_EINVAL;
+    uint32_t k = 0;
+    for (int i = 1; i < IPXK_COUNT; ++i) {
+        if (!h->prof.launches[i]) continue;
+        if (out && k < cap) {
+            memset(&out[k], 0, sizeof out[k]);
+            snprintf(out[k].name, sizeof out[k].name, "%s", kKernelNames[i]);
+            out[k].launches = h->prof.launches[i];
+            out[k].total_ms = h->prof.total_ms[i];
+        }
+        ++k;
+    }
+    *n = k;
     return IPX_OK;
 }
 

@@ -79,6 +79,18 @@ struct GenomeDev {
 
 static inline uint64_t ipx_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// ---- per-kernel event timing (ipx_profile / ipx_profile_read) -----------------
+// Launchers call ipx_prof_mark(stream, id) right after a launch; the interval since
+// the previous mark on the stream is charged to `id`.  A no-op unless profiling is on.
+enum IpxKernelId {
+    IPXK_BEGIN = 0,      // opens an interval (after a host sync); never charged
+    IPXK_SCAN, IPXK_SORT_HIST, IPXK_SORT_SCAN, IPXK_SORT_SKIP, IPXK_SORT_SCATTER,
+    IPXK_COUNT_HEADS, IPXK_SCAN_U32, IPXK_WRITE_HEADS, IPXK_MOTIF, IPXK_MEMSET, IPXK_PHASE_A,
+    IPXK_PHASE_B, IPXK_FINISH_J, IPXK_BINS, IPXK_EMIT_BINS, IPXK_EMIT_J, IPXK_EMIT_IJUNC,
+    IPXK_COPY, IPXK_COUNT
+};
+void ipx_prof_mark(hipStream_t s, int id);
+
 // ---- launchers implemented in the kernel translation units -------------------
 // ipx_scan.hip
 hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,

@@ -470,6 +470,7 @@ hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
     hipLaunchKernelGGL(k_count_heads, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
                        si.n_digits, si.n, chunk_j, chunk_b);
+    ipx_prof_mark(s, IPXK_COUNT_HEADS);
     return hipGetLastError();
 }
 
@@ -481,8 +482,10 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
                        si.n_digits, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
                        rb.bin_j, rb.bin_off);
+    ipx_prof_mark(s, IPXK_WRITE_HEADS);
     hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
                        rb.jstart, rb.jend, rb.jmotif);
+    ipx_prof_mark(s, IPXK_MOTIF);
     hipError_t e;
     if ((e = hipMemsetAsync(rb.first, 0xff, sizeof(uint64_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.creator, 0xff, sizeof(uint64_t) * J, s)) != hipSuccess) return e;
@@ -491,27 +494,34 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     if ((e = hipMemsetAsync(rb.counts, 0, sizeof(uint64_t) * 3 * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.jnb, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.bin_count, 0, sizeof(uint32_t) * B, s)) != hipSuccess) return e;
+    ipx_prof_mark(s, IPXK_MEMSET);
     hipLaunchKernelGGL(k_phase_a, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
                        si.n_digits, si.n, pays, rb.chunk_j, rb.jmotif, sj_filter, rb.first, rb.creator);
+    ipx_prof_mark(s, IPXK_PHASE_A);
     hipLaunchKernelGGL(k_phase_b, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
                        si.n_digits, si.n, pays, rb.chunk_j, rb.chunk_b, rb.creator, rb.counts, rb.amin,
                        rb.amax, rb.bin_count, counters);
+    ipx_prof_mark(s, IPXK_PHASE_B);
     hipLaunchKernelGGL(k_finish_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.first, rb.creator,
                        rb.jmotif, rb.jvalid, rb.jstrand, counters);
+    ipx_prof_mark(s, IPXK_FINISH_J);
     hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_j, rb.bin_flag,
                        rb.jnb);
+    ipx_prof_mark(s, IPXK_BINS);
     // compaction offsets: junctions, bins, bins per junction
     if ((e = ipx_launch_scan_u32(s, rb.jvalid, rb.jpos, J, rb.scan_sums, rb.totals + 0)) != hipSuccess) return e;
     if ((e = ipx_launch_scan_u32(s, rb.bin_flag, rb.bin_pos, B, rb.scan_sums, rb.totals + 1)) != hipSuccess) return e;
     if ((e = ipx_launch_scan_u32(s, rb.jnb, rb.jnb, J, rb.scan_sums, nullptr)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
                        rb.bin_pos, rb.out_hist_value, rb.out_hist_count);
+    ipx_prof_mark(s, IPXK_EMIT_BINS);
     TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
                 rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
                 rb.out_creator_index, rb.out_hist_begin, rb.out_ijunc};
     hipLaunchKernelGGL(k_emit_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
                        rb.jnb, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a);
+    ipx_prof_mark(s, IPXK_EMIT_J);
     return hipGetLastError();
 }
 
@@ -520,6 +530,7 @@ hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *a
     if (n_valid == 0) return hipSuccess;
     hipLaunchKernelGGL(k_emit_ijunc, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, a, b, pass_skip,
                        n_digits, ijunc);
+    ipx_prof_mark(s, IPXK_EMIT_IJUNC);
     return hipGetLastError();
 }
 

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint32_t
 
 }  // namespace
 
-hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
-                               uint32_t *block_sums, uint32_t *total) {
+static hipError_t scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
+                           uint32_t *block_sums, uint32_t *total, int prof_id) {
     if (n == 0) {
         if (total) return hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return hipSuccess;
@@ -235,7 +235,13 @@ hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out,
     hipLaunchKernelGGL(k_scan_sums, dim3((uint32_t)m), dim3(256), 0, s, in, n, block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, m, total);
     hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)m), dim3(256), 0, s, in, out, n, block_sums);
+    ipx_prof_mark(s, prof_id);
     return hipGetLastError();
+}
+
+hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
+                               uint32_t *block_sums, uint32_t *total) {
+    return scan_u32(s, in, out, n, block_sums, total, IPXK_SCAN_U32);
 }
 
 // workspace: hist[256 * n_tiles] + scan block sums
@@ -258,11 +264,14 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint64_t n
     for (uint32_t d = 0; d < n_digits; ++d) {
         hipLaunchKernelGGL(k_hist, dim3(n_tiles), dim3(SORT_THREADS), 0, s, buf_a, buf_b, n, d,
                            pass_skip, hist, n_tiles);
-        e = ipx_launch_scan_u32(s, hist, hist, (uint64_t)256 * n_tiles, sums, nullptr);
+        ipx_prof_mark(s, IPXK_SORT_HIST);
+        e = scan_u32(s, hist, hist, (uint64_t)256 * n_tiles, sums, nullptr, IPXK_SORT_SCAN);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_skip, dim3(1), dim3(256), 0, s, hist, n_tiles, n, d, pass_skip);
+        ipx_prof_mark(s, IPXK_SORT_SKIP);
         hipLaunchKernelGGL(k_scatter, dim3(n_tiles), dim3(SORT_THREADS), 0, s, buf_a, buf_b, n, d,
                            pass_skip, hist, n_tiles);
+        ipx_prof_mark(s, IPXK_SORT_SCATTER);
     }
     return hipGetLastError();
 }

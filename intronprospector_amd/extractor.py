@@ -139,6 +139,17 @@ class JunctionsExtractor:
         self.lib.ipx_last_timing(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def profile(self, enable=True):
+        """Switch per-kernel HIP-event timing on/off (resets the sums)."""
+        self._check(self.lib.ipx_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        """-> {kernel name: (launches, total_ms)} since profile(True)."""
+        arr = (L.KernelStat * 32)()
+        n = C.c_uint32(0)
+        self._check(self.lib.ipx_profile_read(self.h, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 32))}
+
     def clear(self):
         self._check(self.lib.ipx_clear(self.h))
 

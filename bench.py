@@ -118,16 +118,21 @@ def main():
         merger = distributed.TableMerger(dev)
 
     n_records = [0]
+    n_merged = [0]
 
     def step():
         ex.clear()
         ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
+        if merger is not None:
+            # partial tables of this rank's shard -> RCCL merge of the junction tables
+            merged, table = merger.merge(ex, rank * n)
+            n_records[0] = table.n_records
+            n_merged[0] = int(merged["target"].shape[0])
+            return table
         rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
         if rc:
             ex._check(rc)
         n_records[0] = table.n_records
-        if merger is not None:
-            merger.merge(ex, table, rank, world)
         return table
 
     for _ in range(args.warmup):
@@ -149,7 +154,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    n_junctions = int(table.n_junctions)
+    n_junctions = n_merged[0] if world > 1 else int(table.n_junctions)
     r = int(n_records[0])
 
     if rank == 0:

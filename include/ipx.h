@@ -141,7 +141,8 @@ typedef struct ipx_table {
     const uint8_t  *strand;        /* Junction::strand after correct_strand() */
     const uint16_t *motif;         /* IPX_MOTIF_* */
     const uint64_t *read_counts;   /* 3 per junction: single, multi, unsure */
-    const uint64_t *creator_index; /* global read index of the creating record */
+    const uint64_t *creator_order; /* creating record: read_index << 20 | number of the
+                                      record inside its alignment; orders creations */
     const uint32_t *ijunc;         /* rank of creation inside this table; the
                                       caller adds the run's running ijunc_
                                       (junctions_extractor.hh:129,202)             */
@@ -216,12 +217,21 @@ int ipx_last_error(const ipx_handle *h, ipx_error *out);
 /* --- multi-GPU support: partial tables over a contiguous shard
  * of the run's alignments, to be combined with RCCL by the caller ------------ */
 
-/* Like ipx_finalize(IPX_MEM_DEVICE) but for one shard of a larger run: returns
- * in addition, per junction, the tallies over ALL the shard's records of the key
- * (what the junction receives if an earlier shard created it).  `out_all` rows
- * correspond 1:1 to keys[]; a key none of whose records passes the filter has
- * creator_index == UINT64_MAX in `out`. */
-int ipx_finalize_shard(ipx_handle *h, ipx_table *out_from_creator, ipx_table *out_all);
+/* ipx_finalize for ONE contiguous shard of a larger run.  A shard cannot know
+ * whether an earlier shard already created a key, so two tables come back, rows
+ * in the same key order:
+ *   out_from_creator  what ipx_finalize returns: keys with a creating record in
+ *                     this shard, tallies from that record on;
+ *   out_all           every key of the shard with the tallies over ALL its records:
+ *                     what the junction receives when an earlier shard created it.
+ * When no record can fail the filter (no genome, or sj_filter != canon) the two
+ * are the same table (same pointers).  The caller combines shards: the creator is
+ * the smallest creator_order over shards; shards before it contribute nothing,
+ * that shard its from_creator row, later shards their out_all row. */
+int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creator, ipx_table *out_all);
+
+/* copy between any two of {host, device} on the handle's stream, then wait */
+int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes);
 
 /* device timing of the last ipx_push_batch / ipx_finalize in milliseconds,
  * measured with HIP events on the handle's stream */

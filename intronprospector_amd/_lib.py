@@ -22,7 +22,7 @@ MOTIF_PRESENT, MOTIF_NONACGT, MOTIF_CANON_P, MOTIF_CANON_RC = 0x8000, 0x4000, 0x
 SYMBOLS = [
     "ipx_abi_version", "ipx_create", "ipx_destroy", "ipx_set_targets", "ipx_set_genome_2bit",
     "ipx_reserve", "ipx_push_batch", "ipx_finalize", "ipx_clear", "ipx_last_error",
-    "ipx_finalize_shard", "ipx_last_timing", "ipx_profile", "ipx_profile_read",
+    "ipx_finalize_shard", "ipx_copy", "ipx_last_timing", "ipx_profile", "ipx_profile_read",
 ]
 
 
@@ -49,7 +49,7 @@ class Table(C.Structure):
         ("n_junctions", C.c_uint64),
         ("target", C.c_void_p), ("intron_start", C.c_void_p), ("intron_end", C.c_void_p),
         ("anchor_start", C.c_void_p), ("anchor_end", C.c_void_p), ("strand", C.c_void_p),
-        ("motif", C.c_void_p), ("read_counts", C.c_void_p), ("creator_index", C.c_void_p),
+        ("motif", C.c_void_p), ("read_counts", C.c_void_p), ("creator_order", C.c_void_p),
         ("ijunc", C.c_void_p), ("hist_begin", C.c_void_p), ("hist_value", C.c_void_p),
         ("hist_count", C.c_void_p), ("n_hist", C.c_uint64),
         ("n_alignments", C.c_uint64), ("n_records", C.c_uint64), ("memory", C.c_int32),
@@ -93,7 +93,8 @@ def load():
     lib.ipx_finalize.argtypes = [vp, C.c_int32, C.POINTER(Table)]
     lib.ipx_clear.argtypes = [vp]
     lib.ipx_last_error.argtypes = [vp, C.POINTER(Error)]
-    lib.ipx_finalize_shard.argtypes = [vp, C.POINTER(Table), C.POINTER(Table)]
+    lib.ipx_finalize_shard.argtypes = [vp, C.c_int32, C.POINTER(Table), C.POINTER(Table)]
+    lib.ipx_copy.argtypes = [vp, vp, vp, C.c_uint64]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ipx_profile.argtypes = [vp, C.c_int]
     lib.ipx_profile_read.argtypes = [vp, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]

@@ -102,11 +102,11 @@ struct ipx_handle {
     uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
     uint64_t seen_words = 0, seen_records = 0;     // for the capacity estimate
     uint64_t reserved_records = 0;
-    DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small;
+    DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2;
     // pinned host
     void *pin_small = nullptr;     // 256 bytes of read-back scalars
-    void *pin_out = nullptr;
-    size_t pin_out_cap = 0;
+    void *pin_out = nullptr, *pin_out2 = nullptr;
+    size_t pin_out_cap = 0, pin_out2_cap = 0;
     ipx_table table{};
     ipx_error err{};
     float push_ms = 0.f, fin_ms = 0.f;
@@ -314,10 +314,11 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays,
                       &h->counters, &h->stage, &h->sort_ws, &h->pass_skip, &h->scratch, &h->out_arena,
-                      &h->rank_skip, &h->d_small})
+                      &h->rank_skip, &h->d_small, &h->out_arena2})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_out2) (void)hipHostFree(h->pin_out2);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -494,11 +495,14 @@ int ipx_last_timing(const ipx_handle *h, float *push_ms, float *finalize_ms) {
     return IPX_OK;
 }
 
-int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
-    if (!h || !out || (memory != IPX_MEM_HOST && memory != IPX_MEM_DEVICE)) return IPX_EINVAL;
-    (void)hipSetDevice(h->params.device);
+// Shared by ipx_finalize and ipx_finalize_shard.
+//   resort      : sort the records and count segment heads (false: reuse the state left by
+//                 the previous call on the same records)
+//   sj_filter   : filter the reduce applies (the shard's "all" table forces IPX_SJ_ALL)
+//   out_arena   : device buffer that receives the table
+static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_filter, DevBuf &out_arena,
+                         void **pin_out, size_t *pin_out_cap, ipx_table *out, unsigned long long *err_out) {
     memset(out, 0, sizeof *out);
-    memset(&h->err, 0, sizeof h->err);
     const uint64_t R = h->n_records;
     int rc;
     hipStream_t s = h->stream;
@@ -509,7 +513,6 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
 
     ProfScope prof_scope(&h->prof);
     ipx_prof_mark(s, IPXK_BEGIN);
-    HIPCHK(hipEventRecord(h->ev[2], s));
     if (R > 0) {
         // one workspace serves the sort (digit histograms) and, once the sort is done,
         // the per-chunk head counts of the reduce
@@ -518,19 +521,22 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
         const uint64_t sums1 = ipx_div_up(chunks, 4096) + 2;
         const size_t ws_bytes = std::max(ipx_sort_workspace_bytes(R),
                                          (size_t)((2 * chunks_al + sums1) * sizeof(uint32_t) + 1024));
-        if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
-        if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
-        HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), R, h->key.n_digits,
-                               h->sort_ws.p, h->sort_ws.cap, h->pass_skip.as<uint32_t>()));
+        if (resort) {
+            if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
+            if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
+            HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), R, h->key.n_digits,
+                                   h->sort_ws.p, h->sort_ws.cap, h->pass_skip.as<uint32_t>()));
+        }
         SortedItems si{h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->pass_skip.as<uint32_t>(), h->key.n_digits, R};
-
         uint32_t *chunk_j = h->sort_ws.as<uint32_t>();
         uint32_t *chunk_b = chunk_j + chunks_al;
         uint32_t *sums = chunk_b + chunks_al;
         uint32_t *tot = h->d_small.as<uint32_t>();
-        HIPCHK(ipx_launch_count_heads(s, si, chunk_j, chunk_b));
-        HIPCHK(ipx_launch_scan_u32(s, chunk_j, chunk_j, chunks, sums, tot + 0));
-        HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
+        if (resort) {
+            HIPCHK(ipx_launch_count_heads(s, si, chunk_j, chunk_b));
+            HIPCHK(ipx_launch_scan_u32(s, chunk_j, chunk_j, chunks, sums, tot + 0));
+            HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
+        }
         HIPCHK(hipMemcpyAsync(small, tot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->prof.collect();
@@ -560,7 +566,7 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
             rb.out_intron_end = outa.take<uint32_t>(J); rb.out_anchor_start = outa.take<uint32_t>(J);
             rb.out_anchor_end = outa.take<uint32_t>(J); rb.out_strand = outa.take<uint8_t>(J);
             rb.out_motif = outa.take<uint16_t>(J); rb.out_read_counts = outa.take<uint64_t>(3ull * J);
-            rb.out_creator_index = outa.take<uint64_t>(J); rb.out_hist_begin = outa.take<uint64_t>((uint64_t)J + 1);
+            rb.out_creator_order = outa.take<uint64_t>(J); rb.out_hist_begin = outa.take<uint64_t>((uint64_t)J + 1);
             rb.out_ijunc = outa.take<uint32_t>(J); rb.out_hist_value = outa.take<uint16_t>(B);
             rb.out_hist_count = outa.take<uint32_t>(B);
         };
@@ -568,11 +574,11 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
             Arena tmp, outa;
             layout(tmp, outa);
             if ((rc = ensure(h, h->scratch, tmp.off + 256))) return rc;
-            if ((rc = ensure(h, h->out_arena, outa.off + 256))) return rc;
+            if ((rc = ensure(h, out_arena, outa.off + 256))) return rc;
             Arena tmp2, outa2;
             tmp2.measuring = outa2.measuring = false;
             tmp2.base = h->scratch.as<char>();
-            outa2.base = h->out_arena.as<char>();
+            outa2.base = out_arena.as<char>();
             layout(tmp2, outa2);
         }
         GenomeDev g{};
@@ -581,7 +587,7 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
             g.seq_len = h->d_seq_len.as<int64_t>(); g.seq_word2 = h->d_seq_word2.as<uint64_t>();
             g.seq_wordm = h->d_seq_wordm.as<uint64_t>(); g.seq_of_rank = h->d_seq_of_rank.as<int32_t>();
         }
-        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->key, rb, g, h->params.sj_filter,
+        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));
         HIPCHK(hipMemcpyAsync(small, rb.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -610,7 +616,6 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
         HIPCHK(hipStreamSynchronize(s));
         err_word = ((const Counters *)(small + 4))->err_word;
     }
-    HIPCHK(hipEventRecord(h->ev[3], s));
 
     ipx_table t{};
     t.n_junctions = n_valid;
@@ -621,18 +626,17 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
     if (memory == IPX_MEM_DEVICE || R == 0) {
         t.target = rb.out_target; t.intron_start = rb.out_intron_start; t.intron_end = rb.out_intron_end;
         t.anchor_start = rb.out_anchor_start; t.anchor_end = rb.out_anchor_end; t.strand = rb.out_strand;
-        t.motif = rb.out_motif; t.read_counts = rb.out_read_counts; t.creator_index = rb.out_creator_index;
+        t.motif = rb.out_motif; t.read_counts = rb.out_read_counts; t.creator_order = rb.out_creator_order;
         t.ijunc = rb.out_ijunc; t.hist_begin = rb.out_hist_begin; t.hist_value = rb.out_hist_value;
         t.hist_count = rb.out_hist_count;
         HIPCHK(hipStreamSynchronize(s));
     } else {
         // pinned host copy, same section layout
         Arena ha;
-        ha.measuring = true;
         for (int pass = 0; pass < 2; ++pass) {
             ha.off = 0;
             ha.measuring = (pass == 0);
-            ha.base = (char *)h->pin_out;
+            ha.base = (char *)*pin_out;
             uint32_t *p_target = ha.take<uint32_t>(n_valid), *p_is = ha.take<uint32_t>(n_valid),
                      *p_ie = ha.take<uint32_t>(n_valid), *p_as = ha.take<uint32_t>(n_valid),
                      *p_ae = ha.take<uint32_t>(n_valid);
@@ -644,12 +648,12 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
             uint16_t *p_hv = ha.take<uint16_t>(n_hist);
             uint32_t *p_hc = ha.take<uint32_t>(n_hist);
             if (pass == 0) {
-                if (ha.off + 256 > h->pin_out_cap) {
-                    if (h->pin_out) (void)hipHostFree(h->pin_out);
-                    h->pin_out = nullptr;
-                    h->pin_out_cap = 0;
-                    HIPCHK(hipHostMalloc(&h->pin_out, ha.off + 256, hipHostMallocDefault));
-                    h->pin_out_cap = ha.off + 256;
+                if (ha.off + 256 > *pin_out_cap) {
+                    if (*pin_out) (void)hipHostFree(*pin_out);
+                    *pin_out = nullptr;
+                    *pin_out_cap = 0;
+                    HIPCHK(hipHostMalloc(pin_out, ha.off + 256, hipHostMallocDefault));
+                    *pin_out_cap = ha.off + 256;
                 }
                 continue;
             }
@@ -663,7 +667,7 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
             D2H(p_strand, rb.out_strand, n_valid, uint8_t);
             D2H(p_motif, rb.out_motif, n_valid, uint16_t);
             D2H(p_counts, rb.out_read_counts, 3ull * n_valid, uint64_t);
-            D2H(p_creator, rb.out_creator_index, n_valid, uint64_t);
+            D2H(p_creator, rb.out_creator_order, n_valid, uint64_t);
             D2H(p_hb, rb.out_hist_begin, (uint64_t)n_valid + 1, uint64_t);
             D2H(p_ijunc, rb.out_ijunc, n_valid, uint32_t);
             D2H(p_hv, rb.out_hist_value, n_hist, uint16_t);
@@ -672,49 +676,67 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
             HIPCHK(hipStreamSynchronize(s));
             t.target = p_target; t.intron_start = p_is; t.intron_end = p_ie; t.anchor_start = p_as;
             t.anchor_end = p_ae; t.strand = p_strand; t.motif = p_motif; t.read_counts = p_counts;
-            t.creator_index = p_creator; t.ijunc = p_ijunc; t.hist_begin = p_hb; t.hist_value = p_hv;
+            t.creator_order = p_creator; t.ijunc = p_ijunc; t.hist_begin = p_hb; t.hist_value = p_hv;
             t.hist_count = p_hc;
         }
     }
-    (void)hipEventElapsedTime(&h->fin_ms, h->ev[2], h->ev[3]);
     h->prof.collect();
-    h->table = t;
     *out = t;
-    if (err_word != IPX_ERRW_NONE) {
-        fill_data_error(h, err_word);
-        if (h->err.kind == IPX_DATA_GENOME_MISSING || h->err.kind == IPX_DATA_GENOME_SHORT) {
-            const uint32_t *d4 = small + 16;
-            const uint32_t rank = d4[0];
-            h->err.target = (rank < h->tid_of_rank.size()) ? h->tid_of_rank[rank] : 0xffffffffu;
-            // the acceptor side [end-2,end) is fetched first (GCC argument order); it is the
-            // failing fetch unless only the donor side runs off the end (cannot happen: start < end)
-            const int64_t e = (int64_t)(int32_t)d4[2], st = (int64_t)(int32_t)d4[1];
-            int64_t L = -1;
-            if (h->err.target != 0xffffffffu) {
-                const std::string &nm = h->names[h->err.target];
-                for (size_t g = 0; g < h->gnames.size(); ++g)
-                    if (h->gnames[g] == nm) { L = h->glen[g]; break; }
-            }
-            auto clamp_len = [&](int64_t beg, int64_t endi) -> int64_t {   // faidx_adjust_position
-                if (endi < beg) beg = endi;
-                if (beg < 0) beg = 0; else if (L <= beg) beg = L;
-                if (endi < 0) endi = 0; else if (L <= endi) endi = L - 1;
-                return endi + 1 - beg > 0 ? endi + 1 - beg : 0;
-            };
-            int64_t fs = e - 2, fe = e;
-            int64_t got = (L >= 0) ? clamp_len(fs, fe - 1) : -2;
-            if (L >= 0 && got == 2) { fs = st; fe = st + 2; got = clamp_len(fs, fe - 1); }
-            h->err.start = (uint32_t)fs;
-            h->err.end = (uint32_t)fe;
-            h->err.retlen = (int32_t)got;
-            const char *nm = (h->err.target != 0xffffffffu) ? h->names[h->err.target].c_str() : "?";
-            if (h->err.kind == IPX_DATA_GENOME_MISSING)
-                snprintf(h->err.detail, sizeof h->err.detail, "can't load genome sequence for: %s:%d-%d", nm, (int)fs, (int)fe);
-            else
-                snprintf(h->err.detail, sizeof h->err.detail, "unexpected length returned for: %s:%d-%d: %d", nm, (int)fs, (int)fe, (int)got);
+    *err_out = err_word;
+    return IPX_OK;
+}
+
+// turn the device's earliest-error word into ipx_error and the reference's message
+static int report_data_error(ipx_handle *h, unsigned long long err_word) {
+    uint32_t *small = (uint32_t *)h->pin_small;
+    fill_data_error(h, err_word);
+    if (h->err.kind == IPX_DATA_GENOME_MISSING || h->err.kind == IPX_DATA_GENOME_SHORT) {
+        const uint32_t *d4 = small + 16;
+        const uint32_t rank = d4[0];
+        h->err.target = (rank < h->tid_of_rank.size()) ? h->tid_of_rank[rank] : 0xffffffffu;
+        // the acceptor side [end-2,end) is fetched first (g++ evaluates the operands of
+        // fetch(a) + "/" + fetch(b) right to left, junctions_extractor.cc:419-420)
+        const int64_t e = (int64_t)(int32_t)d4[2], st = (int64_t)(int32_t)d4[1];
+        int64_t L = -1;
+        if (h->err.target != 0xffffffffu) {
+            const std::string &nm = h->names[h->err.target];
+            for (size_t g = 0; g < h->gnames.size(); ++g)
+                if (h->gnames[g] == nm) { L = h->glen[g]; break; }
         }
-        return IPX_EDATA;
+        auto clamp_len = [&](int64_t beg, int64_t endi) -> int64_t {   // faidx_adjust_position
+            if (endi < beg) beg = endi;
+            if (beg < 0) beg = 0; else if (L <= beg) beg = L;
+            if (endi < 0) endi = 0; else if (L <= endi) endi = L - 1;
+            return endi + 1 - beg > 0 ? endi + 1 - beg : 0;
+        };
+        int64_t fs = e - 2, fe = e;
+        int64_t got = (L >= 0) ? clamp_len(fs, fe - 1) : -2;
+        if (L >= 0 && got == 2) { fs = st; fe = st + 2; got = clamp_len(fs, fe - 1); }
+        h->err.start = (uint32_t)fs;
+        h->err.end = (uint32_t)fe;
+        h->err.retlen = (int32_t)got;
+        const char *nm = (h->err.target != 0xffffffffu) ? h->names[h->err.target].c_str() : "?";
+        if (h->err.kind == IPX_DATA_GENOME_MISSING)
+            snprintf(h->err.detail, sizeof h->err.detail, "can't load genome sequence for: %s:%d-%d", nm, (int)fs, (int)fe);
+        else
+            snprintf(h->err.detail, sizeof h->err.detail, "unexpected length returned for: %s:%d-%d: %d", nm, (int)fs, (int)fe, (int)got);
     }
+    return IPX_EDATA;
+}
+
+int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
+    if (!h || !out || (memory != IPX_MEM_HOST && memory != IPX_MEM_DEVICE)) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    memset(&h->err, 0, sizeof h->err);
+    unsigned long long err_word = IPX_ERRW_NONE;
+    (void)hipEventRecord(h->ev[2], h->stream);
+    int rc = finalize_core(h, memory, true, h->params.sj_filter, h->out_arena, &h->pin_out, &h->pin_out_cap, out, &err_word);
+    if (rc) return rc;
+    (void)hipEventRecord(h->ev[3], h->stream);
+    (void)hipEventSynchronize(h->ev[3]);
+    (void)hipEventElapsedTime(&h->fin_ms, h->ev[2], h->ev[3]);
+    h->table = *out;
+    if (err_word != IPX_ERRW_NONE) return report_data_error(h, err_word);
     return IPX_OK;
 }
 
@@ -747,9 +769,39 @@ int ipx_profile_read(const ipx_handle *h, ipx_kernel_stat *out, uint32_t cap, ui
     return IPX_OK;
 }
 
-int ipx_finalize_shard(ipx_handle *h, ipx_table *out_from_creator, ipx_table *out_all) {
-    (void)out_from_creator; (void)out_all;
-    return fail(h, IPX_EINVAL, "ipx_finalize_shard: not implemented yet%s%ld", "", 0);
+int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creator, ipx_table *out_all) {
+    if (!h || !out_from_creator || !out_all || (memory != IPX_MEM_HOST && memory != IPX_MEM_DEVICE)) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    memset(&h->err, 0, sizeof h->err);
+    unsigned long long err_word = IPX_ERRW_NONE, err2 = IPX_ERRW_NONE;
+    (void)hipEventRecord(h->ev[2], h->stream);
+    int rc = finalize_core(h, memory, true, h->params.sj_filter, h->out_arena, &h->pin_out, &h->pin_out_cap,
+                           out_from_creator, &err_word);
+    if (rc) return rc;
+    // Every record passes when there is no motif to test or the filter is not "canon":
+    // then the two tables are the same table.
+    const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
+    if (filter_active) {
+        rc = finalize_core(h, memory, false, IPX_SJ_ALL, h->out_arena2, &h->pin_out2, &h->pin_out2_cap, out_all, &err2);
+        if (rc) return rc;
+    } else {
+        *out_all = *out_from_creator;
+    }
+    (void)hipEventRecord(h->ev[3], h->stream);
+    (void)hipEventSynchronize(h->ev[3]);
+    (void)hipEventElapsedTime(&h->fin_ms, h->ev[2], h->ev[3]);
+    h->table = *out_from_creator;
+    if (err_word != IPX_ERRW_NONE) return report_data_error(h, err_word);
+    return IPX_OK;
+}
+
+int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes) {
+    if (!h || (bytes && (!dst || !src))) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    if (!bytes) return IPX_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return IPX_OK;
 }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ struct ReduceBuffers {
     uint32_t *out_target, *out_intron_start, *out_intron_end, *out_anchor_start, *out_anchor_end;
     uint8_t *out_strand;
     uint16_t *out_motif;
-    uint64_t *out_read_counts, *out_creator_index, *out_hist_begin;
+    uint64_t *out_read_counts, *out_creator_order, *out_hist_begin;
     uint32_t *out_ijunc;
     uint16_t *out_hist_value;
     uint32_t *out_hist_count;

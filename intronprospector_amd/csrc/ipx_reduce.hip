@@ -399,7 +399,7 @@ struct TableDev {
     uint32_t *target, *intron_start, *intron_end, *anchor_start, *anchor_end;
     uint8_t *strand;
     uint16_t *motif;
-    uint64_t *read_counts, *creator_index, *hist_begin;
+    uint64_t *read_counts, *creator_order, *hist_begin;
     uint32_t *ijunc;
 };
 
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     out.read_counts[(uint64_t)o * 3 + 1] = counts[(uint64_t)j * 3 + 1];
     out.read_counts[(uint64_t)o * 3 + 2] = counts[(uint64_t)j * 3 + 2];
     const unsigned long long cr = creator[j];
-    out.creator_index[o] = IPX_ORD_READ(cr);
+    out.creator_order[o] = IPX_ORD_SEQ(cr);
     out.hist_begin[o] = jnb_scan[j];
     // creation order = (read_index, ordinal): sort key for the ijunc ranks
     const unsigned long long seq = IPX_ORD_SEQ(cr);
@@ -517,7 +517,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     ipx_prof_mark(s, IPXK_EMIT_BINS);
     TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
                 rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
-                rb.out_creator_index, rb.out_hist_begin, rb.out_ijunc};
+                rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
     hipLaunchKernelGGL(k_emit_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
                        rb.jnb, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a);

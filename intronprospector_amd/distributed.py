@@ -1,0 +1,201 @@
+"""Combining the partial junction tables of contiguous shards.
+
+Alignments shard naturally: rank g holds a contiguous range of the run's
+alignments and reduces it on its own GPU (ipx_finalize_shard).  The only
+exchange is on the small junction tables, over torch.distributed ("nccl" is RCCL
+over xGMI on MI355X; "gloo" in the CPU tests):
+
+  1. all_gather of the shards' key lists -> sorted union -> dense index
+  2. all_reduce(MIN) of the packed creation order: the global creator of a key
+     is the earliest creating record over all shards
+  3. every shard picks what it contributes to each key -- nothing (shard lies
+     before the creator), its from-creator tallies (it holds the creator) or its
+     all-records tallies (it lies after) -- then all_reduce SUM (counts), MIN
+     (anchor start), MAX (anchor end, motif word)
+  4. all_gather of the contributing histogram bins, summed per (key, offset)
+
+This is NOT Junction::merge (junctions.cc:76-105) of the reference's merge tool,
+whose max-of-confidences rule differs from a single run over the same input.
+Everything here is plumbing on tables of at most a few million rows; torch ops
+are used so the same code runs on CPU tensors under gloo.
+"""
+import torch
+import torch.distributed as dist
+
+BIG = (1 << 62)
+
+
+def _all_gather_var(t, group=None):
+    """all_gather of 1-D/2-D tensors whose first dimension differs per rank."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def _keys(tab):
+    """(n, 2) int64 rows (target << 32 | start, end): row-lexicographic order is the
+    table's key order."""
+    k0 = (tab["target"].to(torch.int64) << 32) | tab["intron_start"].to(torch.int64)
+    return torch.stack([k0, tab["intron_end"].to(torch.int64)], dim=1)
+
+
+def _find_rows(union, keys):
+    """index of each row of `keys` in the sorted unique `union` (all present)."""
+    # union rows are unique and sorted; compare through a single int128-free trick:
+    # search on column 0, then resolve equal-k0 runs with column 1
+    lo = torch.searchsorted(union[:, 0].contiguous(), keys[:, 0].contiguous(), right=False)
+    hi = torch.searchsorted(union[:, 0].contiguous(), keys[:, 0].contiguous(), right=True)
+    idx = lo.clone()
+    # runs of equal (target,start) are short (alternative ends); walk them
+    maxrun = int((hi - lo).max().item()) if keys.shape[0] else 0
+    found = torch.zeros(keys.shape[0], dtype=torch.bool, device=keys.device)
+    for step in range(maxrun):
+        cand = torch.clamp(lo + step, max=union.shape[0] - 1)
+        hit = (~found) & (lo + step < hi) & (union[cand, 1] == keys[:, 1])
+        idx = torch.where(hit, cand, idx)
+        found |= hit
+    assert bool(found.all()) or keys.shape[0] == 0
+    return idx
+
+
+def merge_shard_tables(fc, al, shard_begin_order, group=None):
+    """fc / al: the shard's from-creator and all-records tables as dicts of torch
+    tensors (target,intron_start,intron_end,anchor_start,anchor_end,strand,motif,
+    counts[n,3],creator_order,hist_begin[n+1],hist_value,hist_count).
+    shard_begin_order: smallest creator_order any record of this shard can have
+    (first global read index << 20).  Returns the merged table (same on all ranks),
+    rows in key order, ijunc = rank of creation."""
+    dev = al["target"].device
+    k_al, k_fc = _keys(al), _keys(fc)
+    # 1. union of keys
+    parts = _all_gather_var(k_al, group)
+    allk = torch.cat(parts, dim=0)
+    if allk.shape[0] == 0:
+        empty = {k: v[:0] for k, v in al.items() if k not in ("hist_begin",)}
+        empty["hist_begin"] = torch.zeros(1, dtype=torch.int64, device=dev)
+        empty["ijunc"] = torch.zeros(0, dtype=torch.int64, device=dev)
+        return empty
+    union = torch.unique(allk, dim=0)                      # sorted rows
+    U = union.shape[0]
+    i_al = _find_rows(union, k_al)
+    i_fc = _find_rows(union, k_fc)
+
+    # 2. global creator: min of (creator_order << 8 | strand)
+    packed = torch.full((U,), BIG, dtype=torch.int64, device=dev)
+    packed[i_fc] = (fc["creator_order"].to(torch.int64) << 8) | fc["strand"].to(torch.int64)
+    mine = packed.clone()
+    dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
+    exists = packed < BIG
+    g_order = packed >> 8
+
+    # 3. contributions
+    is_creator = exists & (mine == packed)
+    after = exists & (g_order < int(shard_begin_order))    # created by an earlier shard
+    counts = torch.zeros((U, 3), dtype=torch.int64, device=dev)
+    amin = torch.full((U,), BIG, dtype=torch.int64, device=dev)
+    amax = torch.zeros((U,), dtype=torch.int64, device=dev)
+    motif = torch.zeros((U,), dtype=torch.int64, device=dev)
+    sel_fc = is_creator[i_fc]
+    sel_al = after[i_al]
+    for tab, idx, sel in ((fc, i_fc, sel_fc), (al, i_al, sel_al)):
+        rows = idx[sel]
+        counts[rows] = tab["counts"][sel].to(torch.int64)
+        amin[rows] = tab["anchor_start"][sel].to(torch.int64)
+        amax[rows] = tab["anchor_end"][sel].to(torch.int64)
+    motif[i_al] = al["motif"].to(torch.int64)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(amin, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(motif, op=dist.ReduceOp.MAX, group=group)
+
+    # 4. histogram bins of the contributing rows
+    def bins_of(tab, idx, sel):
+        hb = tab["hist_begin"].to(torch.int64)
+        nb = hb[1:] - hb[:-1]
+        row_of_bin = torch.repeat_interleave(torch.arange(nb.shape[0], device=dev), nb)
+        keep = sel[row_of_bin]
+        u = idx[row_of_bin[keep]]
+        return (u << 16) | tab["hist_value"][keep].to(torch.int64), tab["hist_count"][keep].to(torch.int64)
+    b1, c1 = bins_of(fc, i_fc, sel_fc)
+    b2, c2 = bins_of(al, i_al, sel_al)
+    bk = torch.cat([b1, b2])
+    bc = torch.cat([c1, c2])
+    bk_all = torch.cat(_all_gather_var(bk, group))
+    bc_all = torch.cat(_all_gather_var(bc, group))
+    ub, inv = torch.unique(bk_all, return_inverse=True)    # sorted by (key index, offset)
+    hc = torch.zeros(ub.shape[0], dtype=torch.int64, device=dev)
+    hc.index_add_(0, inv, bc_all)
+
+    # compact to the junctions that exist
+    rows = torch.nonzero(exists, as_tuple=False).squeeze(1)
+    new_of_old = torch.cumsum(exists.to(torch.int64), 0) - 1
+    bin_row = new_of_old[ub >> 16]
+    n = rows.shape[0]
+    hist_begin = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    hist_begin[1:] = torch.cumsum(torch.bincount(bin_row, minlength=n), 0)
+    order = g_order[rows]
+    ijunc = torch.empty(n, dtype=torch.int64, device=dev)
+    ijunc[torch.argsort(order)] = torch.arange(n, dtype=torch.int64, device=dev)
+    return {
+        "target": union[rows, 0] >> 32, "intron_start": union[rows, 0] & 0xffffffff, "intron_end": union[rows, 1],
+        "anchor_start": amin[rows], "anchor_end": amax[rows], "strand": packed[rows] & 0xff,
+        "motif": motif[rows], "counts": counts[rows], "creator_order": order, "ijunc": ijunc,
+        "hist_begin": hist_begin, "hist_value": ub & 0xffff, "hist_count": hc,
+    }
+
+
+_FIELDS = (("target", torch.int32, 4), ("intron_start", torch.int32, 4), ("intron_end", torch.int32, 4),
+           ("anchor_start", torch.int32, 4), ("anchor_end", torch.int32, 4), ("strand", torch.uint8, 1),
+           ("motif", torch.int16, 2), ("creator_order", torch.int64, 8))
+
+
+def table_to_torch(ex, t, device):
+    """Copy an ipx_table (host or device memory) into torch tensors on `device`."""
+    n, nh = int(t.n_junctions), int(t.n_hist)
+    out = {}
+
+    def grab(ptr, count, dtype, width):
+        x = torch.empty(count, dtype=dtype, device=device)
+        if count:
+            ex._check(ex.lib.ipx_copy(ex.h, x.data_ptr(), ptr, count * width))
+        return x
+    for name, dt, w in _FIELDS:
+        x = grab(getattr(t, name), n, dt, w)
+        if dt == torch.int32:
+            x = x.to(torch.int64) & 0xffffffff
+        elif dt == torch.int16:
+            x = x.to(torch.int64) & 0xffff
+        out[name] = x
+    out["counts"] = grab(t.read_counts, 3 * n, torch.int64, 8).reshape(n, 3)
+    out["hist_begin"] = grab(t.hist_begin, n + 1, torch.int64, 8) if n else torch.zeros(1, dtype=torch.int64, device=device)
+    out["hist_value"] = grab(t.hist_value, nh, torch.int16, 2).to(torch.int64) & 0xffff
+    out["hist_count"] = grab(t.hist_count, nh, torch.int32, 4).to(torch.int64) & 0xffffffff
+    return out
+
+
+class TableMerger:
+    """bench.py / multi-GPU driver: local shard tables -> merged table over RCCL."""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = device, group
+
+    def merge(self, ex, shard_first_read_index):
+        from . import _lib as L
+        import ctypes as C
+        fc, al = L.Table(), L.Table()
+        rc = ex.lib.ipx_finalize_shard(ex.h, L.IPX_MEM_DEVICE, C.byref(fc), C.byref(al))
+        if rc:
+            ex._check(rc)
+        t_fc = table_to_torch(ex, fc, self.device)
+        same = (fc.target == al.target)
+        t_al = t_fc if same else table_to_torch(ex, al, self.device)
+        merged = merge_shard_tables(t_fc, t_al, int(shard_first_read_index) << 20, self.group)
+        return merged, fc

@@ -25,7 +25,7 @@ class IpxError(RuntimeError):
 
 _NP = {
     "target": np.uint32, "intron_start": np.uint32, "intron_end": np.uint32, "anchor_start": np.uint32,
-    "anchor_end": np.uint32, "strand": np.uint8, "motif": np.uint16, "creator_index": np.uint64,
+    "anchor_end": np.uint32, "strand": np.uint8, "motif": np.uint16, "creator_order": np.uint64,
     "ijunc": np.uint32,
 }
 

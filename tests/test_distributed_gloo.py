@@ -1,0 +1,122 @@
+"""Multi-rank table merge on CPU (gloo, world_size 2 and 3): shard tables produced by
+the oracle, merged by the product's protocol, must equal a single oracle run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_table(batch, names, params, fasta):
+    from tests.oracle_binding import Oracle
+    ora = Oracle(targets=names, genome_fasta=fasta, **params)
+    ora.process(batch)
+    t = ora.table()
+    ora.close()
+    return t
+
+
+def _to_torch(t, rank):
+    """oracle table -> the dict merge_shard_tables takes; creation order surrogate
+    (rank << 32 | local ijunc) orders creations like global read indices do for
+    contiguous shards."""
+    n = len(t["intron_start"])
+    row = np.repeat(np.arange(n), t["n_offsets"].astype(np.int64))
+    pair = (row.astype(np.int64) << 16) | t["offsets"].astype(np.int64)
+    ub, cnt = np.unique(pair, return_counts=True)
+    hb = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(ub >> 16, minlength=n), out=hb[1:])
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int64))
+    return {
+        "target": i64(t["target"]), "intron_start": i64(t["intron_start"]), "intron_end": i64(t["intron_end"]),
+        "anchor_start": i64(t["anchor_start"]), "anchor_end": i64(t["anchor_end"]), "strand": i64(t["strand"]),
+        "motif": torch.zeros(n, dtype=torch.int64), "counts": i64(t["counts"]),
+        "creator_order": (rank << 32) | i64(t["ijunc"]),
+        "hist_begin": torch.from_numpy(hb), "hist_value": i64(ub & 0xffff), "hist_count": i64(cnt),
+    }
+
+
+def _worker(rank, world, port, genome, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from intronprospector_amd import synth
+        from intronprospector_amd.distributed import merge_shard_tables
+        import tempfile
+        params, fasta = {}, None
+        if genome:
+            batch, names, gen = synth.short_reads(30_000, seed=21, n_targets=3, target_len=2_800_000, n_sites=400, genome=True)
+            d = tempfile.mkdtemp()
+            fasta = os.path.join(d, "g%d.fa" % rank)
+            gen.write_fasta(fasta)
+            params = {"junction_filter": 2}
+        else:
+            batch, names, _ = synth.short_reads(30_000, seed=22, n_targets=3, target_len=2_800_000, n_sites=400)
+        n = len(batch["tid"])
+        cuts = np.linspace(0, n, world + 1).astype(int)
+        shard = synth.slice_batch(batch, int(cuts[rank]), int(cuts[rank + 1]))
+        fc = _to_torch(_oracle_table(shard, names, params, fasta), rank)
+        p_all = dict(params)
+        if genome:
+            p_all["junction_filter"] = 1
+        al = _to_torch(_oracle_table(shard, names, p_all, fasta), rank) if genome else fc
+        merged = merge_shard_tables(fc, al, rank << 32)
+        if rank == 0:
+            ref = _oracle_table(batch, names, params, fasta)
+            oo = np.lexsort((ref["intron_end"], ref["intron_start"], ref["target"]))
+            ok = True
+            msg = []
+            for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc"):
+                a = merged[k].numpy().astype(np.int64)
+                b = ref[k][oo].astype(np.int64)
+                if a.shape != b.shape or not np.array_equal(a, b):
+                    ok = False
+                    msg.append(k)
+            if ok and not np.array_equal(merged["counts"].numpy().astype(np.uint64), ref["counts"][oo]):
+                ok = False
+                msg.append("counts")
+            if ok:
+                # offsets multisets
+                starts = np.concatenate([[0], np.cumsum(ref["n_offsets"].astype(np.int64))])
+                flat = np.concatenate([ref["offsets"][starts[i]:starts[i + 1]] for i in oo]) if len(oo) else np.zeros(0)
+                got = np.repeat(merged["hist_value"].numpy(), merged["hist_count"].numpy())
+                if not np.array_equal(flat.astype(np.int64), got.astype(np.int64)):
+                    ok = False
+                    msg.append("offsets")
+                hb = merged["hist_begin"].numpy()
+                csum = np.concatenate([[0], np.cumsum(merged["hist_count"].numpy())])
+                if not np.array_equal(csum[hb[1:]] - csum[hb[:-1]], ref["n_offsets"][oo].astype(np.int64)):
+                    ok = False
+                    msg.append("hist_begin")
+            q.put((ok, msg, len(oo)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("genome", [False, True])
+def test_shard_merge_equals_single_run(world, genome, oracle_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, genome, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, msg, n = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok, "merged table differs from the single run in: %s" % msg
+    assert n > 100

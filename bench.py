@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10M for S, 200k for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 path on a one-GPU box (tables merged on the CPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,11 +86,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     import torch
     import torch.distributed as dist
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import intronprospector_amd as ipa
     from intronprospector_amd import synth
@@ -115,7 +122,7 @@ def main():
     merger = None
     if world > 1:
         from intronprospector_amd import distributed
-        merger = distributed.TableMerger(dev)
+        merger = distributed.TableMerger(dev if args.backend == "nccl" else torch.device("cpu"))
 
     n_records = [0]
     n_merged = [0]
@@ -151,7 +158,7 @@ def main():
     stats = ex.profile_read()
     ex.profile(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     n_junctions = n_merged[0] if world > 1 else int(table.n_junctions)

@@ -328,7 +328,14 @@ int ipx_destroy(ipx_handle *h) {
 
 int ipx_set_targets(ipx_handle *h, uint32_t n, const char *const *names, const int64_t *lengths) {
     if (!h || (n && !names)) return IPX_EINVAL;
-    if (h->n_records) return fail(h, IPX_EINVAL, "ipx_set_targets with records pending: call ipx_clear first%s%ld", "", 0);
+    if (h->n_records) {
+        // Records already carry key ranks.  In target scope rank == tid, so a list that only
+        // APPENDS targets (the reference's save_targets on a further open()) keeps them valid.
+        bool extends = h->params.scope == IPX_SCOPE_TARGET && n >= h->names.size();
+        for (size_t i = 0; extends && i < h->names.size(); ++i) extends = names[i] && h->names[i] == names[i];
+        if (!extends)
+            return fail(h, IPX_EINVAL, "ipx_set_targets with records pending: only appending targets in target scope is possible%s%ld", "", 0);
+    }
     (void)hipSetDevice(h->params.device);
     h->names.clear();
     h->target_len.clear();

@@ -1,0 +1,61 @@
+// aln_reader.hh -- alignment decoding: SAM text, gzip'd SAM, and BAM (BGZF).
+//
+// Stands where htslib's sam_open / sam_hdr_read / sam_read1 / bam_aux_get /
+// bam_aux2i / bam_aux2A stand under the reference's read loops
+// (src/junctions_extractor.cc:49-56,322-330,571-586,620-634).  htslib is not part
+// of this image; the decoder is written against the SAM/BAM specification and
+// yields only what the hot path consumes, already in the encoding of
+// include/ipx.h (xs / nh classes, BAM-packed CIGAR words).
+#ifndef IPX_HOST_ALN_READER_HH
+#define IPX_HOST_ALN_READER_HH
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+namespace ipxhost {
+
+struct AlnRecord {
+    int32_t tid = -1;
+    int64_t pos = 0;
+    uint16_t flag = 0;
+    uint8_t xs = 0;        // 0 = no XS tag, else strand byte ('.' if the tag is not of type A)
+    uint8_t nh = 0;        // 0 = no NH / <= 0, 1 = NH == 1, 2 = NH > 1
+    std::vector<uint32_t> cigar;
+    std::string qname;
+};
+
+class AlnReader {
+public:
+    explicit AlnReader(const std::string &path);     // throws std::runtime_error
+    ~AlnReader();
+    AlnReader(const AlnReader &) = delete;
+    AlnReader &operator=(const AlnReader &) = delete;
+
+    const std::vector<std::string> &target_names() const { return names_; }
+    const std::vector<int64_t> &target_lengths() const { return lengths_; }
+    bool is_bam() const { return bam_; }
+    // false at end of input; throws std::runtime_error on a malformed record
+    bool read(AlnRecord &rec);
+
+private:
+    std::string path_;
+    gzFile fh_ = nullptr;
+    bool bam_ = false;
+    std::vector<std::string> names_;
+    std::vector<int64_t> lengths_;
+    // SAM text state
+    std::string line_;
+    bool have_line_ = false;
+    bool read_line();
+    void parse_sam_header();
+    bool read_sam(AlnRecord &rec);
+    // BAM state
+    std::vector<uint8_t> buf_;
+    void read_exact(void *dst, size_t n, const char *what);
+    void parse_bam_header();
+    bool read_bam(AlnRecord &rec);
+};
+
+}  // namespace ipxhost
+#endif

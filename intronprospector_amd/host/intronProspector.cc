@@ -1,0 +1,245 @@
+// intronProspector.cc -- command line of the MI355X build; same options, messages
+// and output scheduling as the reference's driver (src/intronProspector.cc):
+// option table :159-185, defaults :44-50, filter default :274-282, indel switch
+// :289-292, the three drivers :356-401, output_junctions :330-351, error exit :63-67.
+//
+// Not offered (outside the accelerated path): --pass-through,
+// --set-XS-strand-tag, --set-TS-strand-tag, --debug-trace.
+#include <getopt.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "genome.hh"
+#include "gz_ostream.hh"
+#include "junctions.hh"
+#include "junctions_extractor.hh"
+
+using namespace ipxhost;
+using std::cerr;
+using std::endl;
+using std::string;
+
+static const uint32_t DEFAULT_MIN_ANCHOR_LENGTH = 8;
+static const uint32_t DEFAULT_MIN_INTRON_LENGTH = 70;
+static const uint32_t DEFAULT_MAX_INTRON_LENGTH = 500000;
+static const uint32_t DEFAULT_MAX_ANCHOR_INDEL_SIZE = 36;
+static const float DEFAULT_MIN_CONFIDENCE_SCORE = 1.0;
+
+static const char *usage_msg =
+    "intronProspector [options] [readaligns ...]\n"
+    "\n"
+    "Find putative intron junctions in RNA-Seq alignments (SAM or BAM; stdin if omitted).\n"
+    "MI355X build of the junction-extraction path of intronProspector 1.4.0; options:\n"
+    "  -h, --help  -v, --version  -u, --unsorted\n"
+    "  -a, --min-anchor-length=8   -i, --min-intron-length=70   -I, --max-intron-length=500000\n"
+    "  --allow-anchor-indels   --max-anchor-indel-size=36   -C, --min-confidence-score=1.0\n"
+    "  -s, --strandness=UN|RF|FR   -X, --excludes=multi\n"
+    "  -g, --genome-fasta=fasta (needs fasta.fai)   -f, --sj-filter=all|canon   -S, --skip-missing-targets\n"
+    "  -j, --junction-bed=file   -n, --intron-bed=file   -b, --intron-bed6=file   -c, --intron-calls=file\n"
+    "Outputs whose name ends in .gz are gzip-compressed.\n";
+
+static void cmd_error(const string &msg) {
+    cerr << "Error: " << msg << endl;
+    cerr << "Use --help to get usage" << endl;
+    exit(1);
+}
+
+// src/strconvert.hh:33-46, :14-28
+static unsigned toUnsigned(const char *str) {
+    char *end;
+    errno = 0;
+    unsigned long lnum = strtoul(str, &end, 10);
+    if (end == str || *end != '\0') throw std::runtime_error("Invalid unsigned integer \"" + string(str) + "\"");
+    unsigned num = (unsigned)lnum;
+    if (errno != 0 || (unsigned long)num != lnum)
+        throw std::runtime_error("Unsigned integer out of range \"" + string(str) + "\"");
+    return num;
+}
+
+static float toFloat(const char *str) {
+    char *end;
+    errno = 0;
+    float num = strtof(str, &end);
+    if (end == str || *end != '\0' || errno != 0) {
+        if (errno != 0) throw std::runtime_error("Float out of range \"" + string(str) + "\"");
+        throw std::runtime_error("Invalid float \"" + string(str) + "\"");
+    }
+    return num;
+}
+
+struct Options {
+    std::vector<string> bam_files;
+    uint32_t min_anchor_length = DEFAULT_MIN_ANCHOR_LENGTH;
+    uint32_t min_intron_length = DEFAULT_MIN_INTRON_LENGTH;
+    uint32_t max_intron_length = DEFAULT_MAX_INTRON_LENGTH;
+    bool allow_anchor_indels = false;
+    bool unsorted = false;
+    uint32_t max_anchor_indel_size = DEFAULT_MAX_ANCHOR_INDEL_SIZE;
+    float min_confidence_score = DEFAULT_MIN_CONFIDENCE_SCORE;
+    JunctionFilter junction_filter = NULL_SJ_FILTER;
+    Strandness strandness = UNSTRANDED;
+    unsigned excludes = EXCLUDE_NONE;
+    string genome_fa;
+    bool skip_missing_targets = false;
+    string junction_bed, intron_bed, intron_bed6, intron_call_tsv;
+};
+
+static void parse_options(int argc, char *argv[], Options &o) {
+    enum { OPT_XS = 256, OPT_TS = 257 };
+    static const struct option long_options[] = {
+        {"help", no_argument, NULL, 'h'}, {"version", no_argument, NULL, 'v'},
+        {"unsorted", no_argument, NULL, 'u'},
+        {"min-anchor-length", required_argument, NULL, 'a'},
+        {"min-intron-length", required_argument, NULL, 'i'},
+        {"max-intron-length", required_argument, NULL, 'I'},
+        {"allow-anchor-indels", no_argument, NULL, 'd'},
+        {"max-anchor-indel-size", required_argument, NULL, 'm'},
+        {"min-confidence-score", required_argument, NULL, 'C'},
+        {"strandness", required_argument, NULL, 's'},
+        {"excludes", required_argument, NULL, 'X'},
+        {"genome-fasta", required_argument, NULL, 'g'},
+        {"sj-filter", required_argument, NULL, 'f'},
+        {"skip-missing-targets", no_argument, NULL, 'S'},
+        {"junction-bed", required_argument, NULL, 'j'},
+        {"intron-bed", required_argument, NULL, 'n'},
+        {"intron-bed6", required_argument, NULL, 'b'},
+        {"intron-calls", required_argument, NULL, 'c'},
+        {"pass-through", required_argument, NULL, 'p'},
+        {"debug-trace", required_argument, NULL, 'D'},
+        {"set-XS-strand-tag", no_argument, NULL, OPT_XS},
+        {"set-TS-strand-tag", no_argument, NULL, OPT_TS},
+        {NULL, 0, NULL, 0}};
+    // the reference's short-option string (intronProspector.cc:185), quirks included
+    const char *short_options = "hvua:i:I:C:s:X:g:S:j:n:b:c:p:D:f:";
+    int c;
+    while ((c = getopt_long(argc, argv, short_options, long_options, NULL)) != -1) {
+        switch (c) {
+            case 'a': o.min_anchor_length = (uint32_t)atoi(optarg); break;
+            case 'u': o.unsorted = true; break;
+            case 'd': o.allow_anchor_indels = true; break;
+            case 'm': o.max_anchor_indel_size = toUnsigned(optarg); break;
+            case 'i': o.min_intron_length = toUnsigned(optarg); break;
+            case 'I': o.max_intron_length = toUnsigned(optarg); break;
+            case 'C': o.min_confidence_score = toFloat(optarg); break;
+            case 's': {
+                string su(optarg);
+                std::transform(su.begin(), su.end(), su.begin(), ::toupper);
+                if (su == "UN") o.strandness = UNSTRANDED;
+                else if (su == "RF") o.strandness = RF_STRANDED;
+                else if (su == "FR") o.strandness = FR_STRANDED;
+                else {
+                    cerr << "Error: invalid strandness value '" << optarg
+                         << "', expected one of 'UN', 'RF', or 'FR' (case insensitive)" << endl;
+                    exit(1);
+                }
+                break;
+            }
+            case 'X':
+                if (string(optarg) == "multi") o.excludes |= EXCLUDE_MULTI;
+                else {
+                    cerr << "Error: invalid exclude category '" << optarg << "', expected one of: 'multi'" << endl;
+                    exit(1);
+                }
+                break;
+            case 'g': o.genome_fa = optarg; break;
+            case 'f': o.junction_filter = junction_filter_parse(optarg); break;
+            case 'S': o.skip_missing_targets = true; break;
+            case 'j': o.junction_bed = optarg; break;
+            case 'n': o.intron_bed = optarg; break;
+            case 'b': o.intron_bed6 = optarg; break;
+            case 'c': o.intron_call_tsv = optarg; break;
+            case 'p': case 'D': case OPT_XS: case OPT_TS:
+                cmd_error("--pass-through, --debug-trace and the strand-tag options are not part of the MI355X build");
+                break;
+            case 'h': cerr << usage_msg; exit(0);
+            case 'v': cerr << "intronProspector 1.4.0 (MI355X junction-extraction build)" << endl; exit(0);
+            case '?':
+            default: cmd_error("bug: option not handled");
+        }
+    }
+    for (int i = optind; i < argc; ++i) o.bam_files.push_back(argv[i]);
+    if (o.bam_files.empty()) o.bam_files.push_back("/dev/stdin");
+    if (o.junction_filter == CANON_SJ_FILTER && o.genome_fa.empty()) cmd_error("--sj-filter=canon requires --genome_fa");
+    if (o.junction_filter == NULL_SJ_FILTER && !o.genome_fa.empty()) o.junction_filter = CANON_SJ_FILTER;
+    if (!o.allow_anchor_indels) o.max_anchor_indel_size = 0;
+}
+
+struct OutputFiles {
+    std::unique_ptr<std::ostream> junction_bed_fh, intron_bed_fh, intron_bed6_fh, intron_call_fh;
+    static std::unique_ptr<std::ostream> open(const string &fname) {
+        return fname.empty() ? nullptr : std::unique_ptr<std::ostream>(new AutoGzipOutput(fname));
+    }
+    explicit OutputFiles(const Options &o)
+        : junction_bed_fh(open(o.junction_bed)), intron_bed_fh(open(o.intron_bed)),
+          intron_bed6_fh(open(o.intron_bed6)), intron_call_fh(open(o.intron_call_tsv)) {
+        if (intron_call_fh) print_junction_call_header(*intron_call_fh);       // :317-319
+    }
+};
+
+// src/intronProspector.cc:330-351
+static void output_junctions(JunctionsExtractor &extractor, float min_confidence_score, OutputFiles &output) {
+    JunctionVector juncs = extractor.get_junctions();
+    if (output.junction_bed_fh) {
+        juncs.sort_by_anchors();
+        print_anchor_bed(juncs, min_confidence_score, *output.junction_bed_fh);
+    }
+    if (output.intron_bed_fh || output.intron_bed6_fh || output.intron_call_fh) {
+        juncs.sort_by_introns();
+        if (output.intron_bed_fh) print_intron_bed(juncs, min_confidence_score, 9, *output.intron_bed_fh);
+        if (output.intron_bed6_fh) print_intron_bed(juncs, min_confidence_score, 6, *output.intron_bed6_fh);
+        if (output.intron_call_fh) print_intron_call_tsv(juncs, min_confidence_score, *output.intron_call_fh);
+    }
+}
+
+static void extract_junctions(const Options &o) {
+    std::unique_ptr<Genome> genome;
+    if (!o.genome_fa.empty()) genome.reset(new Genome(o.genome_fa));
+    JunctionsExtractor extractor(o.min_anchor_length, o.max_anchor_indel_size, o.min_intron_length,
+                                 o.max_intron_length, o.junction_filter, o.strandness, o.excludes, genome.get(),
+                                 o.skip_missing_targets);
+    OutputFiles output(o);
+    if (o.bam_files.size() > 1) {                       // :391-401
+        for (const string &bam : o.bam_files) {
+            extractor.open(bam);
+            extractor.identify_junctions_for_bam();
+            extractor.close();
+        }
+        output_junctions(extractor, o.min_confidence_score, output);
+    } else if (o.unsorted) {                            // :375-387
+        extractor.open(o.bam_files[0]);
+        extractor.identify_junctions_for_bam();
+        extractor.close();
+        output_junctions(extractor, o.min_confidence_score, output);
+    } else {                                            // :356-371
+        extractor.open(o.bam_files[0]);
+        for (int target_index = 0; target_index < extractor.get_num_targets(); target_index++) {
+            extractor.identify_junctions_for_target(target_index);
+            output_junctions(extractor, o.min_confidence_score, output);
+            extractor.clear();
+        }
+        extractor.close();
+    }
+}
+
+int main(int argc, char *argv[]) {
+    Options opts;
+    try {
+        parse_options(argc, argv, opts);
+    } catch (const std::exception &ex) {
+        cerr << "Error parsing command line: " << ex.what() << endl;
+        return 1;
+    }
+    try {
+        extract_junctions(opts);
+    } catch (const std::exception &e) {
+        cmd_error(e.what());
+    }
+    return 0;
+}

@@ -1,0 +1,263 @@
+// junctions_extractor.cc -- see junctions_extractor.hh.
+#include "junctions_extractor.hh"
+
+#include <algorithm>
+#include <cctype>
+#include <stdexcept>
+
+namespace ipxhost {
+
+static const size_t BATCH_ALIGNMENTS = 1u << 20;
+
+JunctionFilter junction_filter_parse(const std::string &spec) {
+    if (spec == "all") return ALL_SJ_FILTER;
+    if (spec == "canon") return CANON_SJ_FILTER;
+    throw std::invalid_argument("invalid splice junction filter '" + spec + "', expected 'all' or 'canon'");
+}
+
+JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_anchor_indel_size,
+                                       uint32_t min_intron_length, uint32_t max_intron_length,
+                                       JunctionFilter junction_filter, Strandness strandness, unsigned excludes,
+                                       Genome *genome, bool skip_missing_targets, int device, std::ostream *warn)
+    : genome_(genome), skip_missing_targets_(skip_missing_targets), warn_(warn) {
+    ipx_params p{};
+    p.min_anchor_length = min_anchor_length;
+    p.max_anchor_indel_size = max_anchor_indel_size;
+    p.min_intron_length = min_intron_length;
+    p.max_intron_length = max_intron_length;
+    p.sj_filter = (int32_t)junction_filter;
+    p.strandness = (int32_t)strandness;
+    p.excludes = excludes;
+    // Keys are (first index of the chromosome name, start, end): names that repeat in the
+    // concatenated target vector are folded here, rows are put in std::map order on the host.
+    p.scope = IPX_SCOPE_TARGET;
+    p.skip_missing_targets = skip_missing_targets ? 1 : 0;
+    p.device = device;
+    int rc = ipx_create(&p, &h_);
+    if (rc == IPX_ENODEVICE)
+        throw std::runtime_error("no MI355X (gfx950) device available: this build has no CPU path");
+    if (rc != IPX_OK) throw std::runtime_error("ipx_create failed");
+    if (genome_) {
+        const size_t n = genome_->n_seqs();
+        std::vector<const char *> names(n);
+        std::vector<int64_t> lens(n);
+        std::vector<const uint8_t *> two(n), msk(n);
+        for (size_t i = 0; i < n; ++i) {
+            names[i] = genome_->name(i).c_str();
+            lens[i] = genome_->length(i);
+            two[i] = genome_->twobit(i);
+            msk[i] = genome_->mask(i);
+        }
+        rc = ipx_set_genome_2bit(h_, (uint32_t)n, names.data(), lens.data(), two.data(), msk.data());
+        if (rc != IPX_OK) throw_last_error(rc);
+    }
+}
+
+JunctionsExtractor::~JunctionsExtractor() {
+    if (h_) ipx_destroy(h_);
+}
+
+void JunctionsExtractor::throw_last_error(int status) {
+    ipx_error e;
+    ipx_last_error(h_, &e);
+    const std::string msg = e.detail[0] ? std::string(e.detail) : ("ipx status " + std::to_string(status));
+    if (status == IPX_EDATA) {
+        switch (e.kind) {
+            case IPX_DATA_CIGAR: throw std::invalid_argument(msg);      // junctions_extractor.cc:313
+            case IPX_DATA_CATEGORY: throw std::logic_error(msg);        // :74
+            default: throw std::runtime_error(msg);                     // genome.cc:66,69
+        }
+    }
+    throw std::runtime_error(msg);
+}
+
+// junctions_extractor.cc:571-586 (save_targets :564-568 appends)
+void JunctionsExtractor::open(const std::string &bam) {
+    bam_ = bam;
+    reader_.reset(new AlnReader(bam));
+    for (const std::string &nm : reader_->target_names()) {
+        int32_t first = (int32_t)targets_.size();
+        for (size_t i = 0; i < targets_.size(); ++i)
+            if (targets_[i] == nm) { first = (int32_t)i; break; }
+        targets_.push_back(nm);
+        canon_tid_.push_back(first);
+    }
+    std::vector<const char *> names(targets_.size());
+    for (size_t i = 0; i < targets_.size(); ++i) names[i] = targets_[i].c_str();
+    int rc = ipx_set_targets(h_, (uint32_t)names.size(), names.data(), nullptr);
+    if (rc != IPX_OK) throw_last_error(rc);
+}
+
+// junctions_extractor.cc:605-617
+void JunctionsExtractor::close() {
+    reader_.reset();
+    previous_target_ = -1;
+    aln_pending_ = false;
+}
+
+// junctions_extractor.cc:620-634
+bool JunctionsExtractor::read_align() {
+    if (aln_pending_) {
+        aln_pending_ = false;
+        return true;
+    }
+    return reader_->read(aln_buf_);
+}
+
+// process_alignment (junctions_extractor.cc:533-549) is the device's job: queue the record
+void JunctionsExtractor::process_alignment(const AlnRecord &aln) {
+    int32_t tid = aln.tid;
+    if (tid >= 0 && (size_t)tid < canon_tid_.size()) tid = canon_tid_[tid];
+    b_tid_.push_back(tid);
+    b_pos_.push_back((int32_t)aln.pos);
+    b_flag_.push_back(aln.flag);
+    b_xs_.push_back(aln.xs);
+    b_nh_.push_back(aln.nh);
+    b_off_.push_back((uint32_t)b_cigar_.size());
+    b_nc_.push_back((uint32_t)aln.cigar.size());
+    b_cigar_.insert(b_cigar_.end(), aln.cigar.begin(), aln.cigar.end());
+    table_valid_ = false;
+    if (b_tid_.size() >= BATCH_ALIGNMENTS || b_cigar_.size() >= (1u << 28)) flush_batch();
+}
+
+void JunctionsExtractor::flush_batch() {
+    if (b_tid_.empty()) return;
+    ipx_batch b{};
+    b.n_alignments = b_tid_.size();
+    b.n_cigar_words = b_cigar_.size();
+    b.base_read_index = next_read_index_;
+    b.tid = b_tid_.data(); b.pos = b_pos_.data(); b.flag = b_flag_.data(); b.xs = b_xs_.data();
+    b.nh = b_nh_.data(); b.cigar_off = b_off_.data(); b.n_cigar = b_nc_.data(); b.cigar = b_cigar_.data();
+    b.memory = IPX_MEM_HOST;
+    int rc = ipx_push_batch(h_, &b);
+    next_read_index_ += b.n_alignments;
+    b_tid_.clear(); b_pos_.clear(); b_flag_.clear(); b_xs_.clear(); b_nh_.clear();
+    b_off_.clear(); b_nc_.clear(); b_cigar_.clear();
+    if (rc != IPX_OK) throw_last_error(rc);
+}
+
+// identify_junctions_for_target (junctions_extractor.cc:656-664) with
+// process_target_alignment (:637-652)
+void JunctionsExtractor::identify_junctions_for_target(int target_index) {
+    while (read_align()) {
+        if (aln_buf_.tid != target_index) {
+            if (aln_buf_.tid >= 0 && aln_buf_.tid < previous_target_) {
+                // alignments of this target queued so far are processed first: an exception one of
+                // them raises comes earlier in the input than this one
+                finalize_table();
+                throw std::runtime_error("BAM appears to not be coordinate sorted");
+            }
+            aln_pending_ = true;
+            break;
+        }
+        process_alignment(aln_buf_);
+    }
+    previous_target_ = target_index;
+    finalize_table();       // surfaces the reference's exceptions where its loop would throw
+}
+
+// identify_junctions_for_bam (junctions_extractor.cc:678-683)
+void JunctionsExtractor::identify_junctions_for_bam() {
+    while (read_align()) process_alignment(aln_buf_);
+    finalize_table();
+}
+
+static char complement(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G';
+        case 'a': return 't'; case 't': return 'a'; case 'g': return 'c'; case 'c': return 'g';
+        default: return c;
+    }
+}
+
+void JunctionsExtractor::finalize_table() {
+    flush_batch();
+    ipx_table t;
+    int rc = ipx_finalize(h_, IPX_MEM_HOST, &t);
+    if (rc != IPX_OK) throw_last_error(rc);
+    table_.clear();
+    table_.reserve(t.n_junctions);
+    for (uint64_t i = 0; i < t.n_junctions; ++i) {
+        Junction j;
+        j.chrom = targets_[t.target[i]];
+        j.intron_start = t.intron_start[i];
+        j.intron_end = t.intron_end[i];
+        j.anchor_start = t.anchor_start[i];
+        j.anchor_end = t.anchor_end[i];
+        j.strand = (char)t.strand[i];
+        j.ijunc = ijunc_ + t.ijunc[i];
+        for (int c = 0; c < 3; ++c) j.read_counts[c] = t.read_counts[3 * i + c];
+        // splice_sites as get_splice_sites / correct_strand leave it (junctions_extractor.cc:405-444):
+        // upper(donor/acceptor); reverse-complemented when the junction ends up on '-';
+        // lower-cased when that spelling is not canonical
+        const uint16_t m = t.motif[i];
+        if (m & IPX_MOTIF_PRESENT) {
+            char g[5];
+            if (m & IPX_MOTIF_NONACGT) {
+                g[0] = genome_->raw(j.chrom, j.intron_start); g[1] = genome_->raw(j.chrom, (int64_t)j.intron_start + 1);
+                g[3] = genome_->raw(j.chrom, (int64_t)j.intron_end - 2); g[4] = genome_->raw(j.chrom, (int64_t)j.intron_end - 1);
+            } else {
+                static const char acgt[] = "ACGT";
+                g[0] = acgt[(m >> 6) & 3]; g[1] = acgt[(m >> 4) & 3]; g[3] = acgt[(m >> 2) & 3]; g[4] = acgt[m & 3];
+            }
+            g[2] = '/';
+            for (char &c : g) c = (char)toupper((unsigned char)c);
+            bool canon;
+            if (j.strand == '-') {
+                char r[5];
+                for (int k = 0; k < 5; ++k) r[4 - k] = complement(g[k]);
+                for (int k = 0; k < 5; ++k) g[k] = r[k];
+                canon = (m & IPX_MOTIF_CANON_RC) != 0;
+            } else {
+                canon = (m & IPX_MOTIF_CANON_P) != 0;
+            }
+            if (!canon)
+                for (char &c : g) c = (char)tolower((unsigned char)c);
+            j.splice_sites.assign(g, 5);
+        }
+        const uint64_t hb = t.hist_begin[i], he = t.hist_begin[i + 1];
+        j.confidence = confidence_from_histogram(t.hist_count + hb, he - hb, j.total_read_count());
+        table_.push_back(std::move(j));
+    }
+    // missing-sequence warnings, once per chromosome, in the order the reference meets them
+    // (junctions_extractor.cc:411-416): first record on a chromosome the genome does not hold
+    if (genome_ && skip_missing_targets_) {
+        std::vector<std::pair<uint64_t, std::string>> first_seen;
+        for (uint64_t i = 0; i < t.n_junctions; ++i) {
+            const std::string &chrom = table_[i].chrom;
+            if (genome_->has_seq(chrom) || missing_genomic_warned_.count(chrom)) continue;
+            bool found = false;
+            for (auto &fs : first_seen)
+                if (fs.second == chrom) { fs.first = std::min(fs.first, t.creator_order[i]); found = true; break; }
+            if (!found) first_seen.emplace_back(t.creator_order[i], chrom);
+        }
+        std::sort(first_seen.begin(), first_seen.end());
+        for (auto &fs : first_seen) {
+            missing_genomic_warned_.insert(fs.second);
+            *warn_ << "Warning: genomic sequence not found for " << fs.second << " splice junctions not available" << std::endl;
+        }
+    }
+    // std::map<JunctionKey,...> order: chromosome NAME, start, end (junctions.hh:77-100).  Rows
+    // arrive ordered by (first index of the name, start, end): a stable sort by name finishes it.
+    std::stable_sort(table_.begin(), table_.end(),
+                     [](const Junction &a, const Junction &b) { return a.chrom < b.chrom; });
+    table_valid_ = true;
+}
+
+// JunctionTable::get_junctions, junctions.hh:232-238
+JunctionVector JunctionsExtractor::get_junctions() {
+    if (!table_valid_) finalize_table();
+    return table_;
+}
+
+// JunctionTable::clear via JunctionsExtractor::clear (junctions_extractor.hh:223-225); ijunc_ keeps counting
+void JunctionsExtractor::clear() {
+    if (!table_valid_) finalize_table();
+    ijunc_ += (uint32_t)table_.size();
+    table_.clear();
+    table_valid_ = true;          // an empty table is the table of no records
+    int rc = ipx_clear(h_);
+    if (rc != IPX_OK) throw_last_error(rc);
+}
+
+}  // namespace ipxhost

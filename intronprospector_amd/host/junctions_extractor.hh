@@ -1,0 +1,92 @@
+// junctions_extractor.hh -- host mirror of the reference's JunctionsExtractor
+// (src/junctions_extractor.hh:73-256) on top of the C ABI in include/ipx.h.
+//
+// Same public surface and call order as the reference's only caller uses
+// (src/intronProspector.cc:356-429): construct with the thresholds, open(),
+// identify_junctions_for_target() / identify_junctions_for_bam(), get_junctions(),
+// clear(), close().  The per-alignment work happens on the GPU; this class keeps
+// what stays on the host: the read loops with their one-record look-ahead and
+// sortedness check (junctions_extractor.cc:620-683), the target-name vector that
+// grows with every open() (:564-568), the running ijunc_ (:129,459-460), the
+// missing-sequence warnings (:411-416) and the translation of device error
+// reports into the reference's exceptions.  Pass-through and tag rewriting are not
+// part of the accelerated path and are not offered.
+#ifndef IPX_HOST_JUNCTIONS_EXTRACTOR_HH
+#define IPX_HOST_JUNCTIONS_EXTRACTOR_HH
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/ipx.h"
+#include "aln_reader.hh"
+#include "genome.hh"
+#include "junctions.hh"
+
+namespace ipxhost {
+
+// src/splice_juncs.hh:12-16
+enum JunctionFilter { NULL_SJ_FILTER = 0, ALL_SJ_FILTER = 1, CANON_SJ_FILTER = 2 };
+// src/junctions_extractor.hh:56-60
+enum Strandness { UNSTRANDED = 0, RF_STRANDED = 1, FR_STRANDED = 2 };
+// src/junctions_extractor.hh:64-67
+enum ExcludeCats { EXCLUDE_NONE = 0x00, EXCLUDE_MULTI = 0x01 };
+
+JunctionFilter junction_filter_parse(const std::string &spec);   // src/splice_juncs.cc:41-49
+
+class JunctionsExtractor {
+public:
+    JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_anchor_indel_size, uint32_t min_intron_length,
+                       uint32_t max_intron_length, JunctionFilter junction_filter, Strandness strandness,
+                       unsigned excludes, Genome *genome, bool skip_missing_targets, int device = 0,
+                       std::ostream *warn = &std::cerr);
+    ~JunctionsExtractor();
+    JunctionsExtractor(const JunctionsExtractor &) = delete;
+    JunctionsExtractor &operator=(const JunctionsExtractor &) = delete;
+
+    void open(const std::string &bam);
+    void close();
+    int get_num_targets() const { return (int)targets_.size(); }
+    void identify_junctions_for_target(int target_index);
+    void identify_junctions_for_bam();
+    JunctionVector get_junctions();
+    void clear();
+
+    // alignments handed to the device so far (statistics)
+    uint64_t alignments_processed() const { return next_read_index_; }
+
+private:
+    ipx_handle *h_ = nullptr;
+    Genome *genome_;
+    bool skip_missing_targets_;
+    std::ostream *warn_;
+    std::string bam_;
+    std::vector<std::string> targets_;        // grows with every open()
+    std::vector<int32_t> canon_tid_;          // first index carrying the same name
+    std::set<std::string> missing_genomic_warned_;
+    int previous_target_ = -1;
+    bool aln_pending_ = false;
+    AlnRecord aln_buf_;
+    std::unique_ptr<AlnReader> reader_;
+    uint32_t ijunc_ = 0;
+    uint64_t next_read_index_ = 0;
+    // pending host batch (SoA of include/ipx.h)
+    std::vector<int32_t> b_tid_, b_pos_;
+    std::vector<uint16_t> b_flag_;
+    std::vector<uint8_t> b_xs_, b_nh_;
+    std::vector<uint32_t> b_off_, b_nc_, b_cigar_;
+    // finalized table of the records pushed since the last clear()
+    bool table_valid_ = false;
+    JunctionVector table_;
+
+    bool read_align();
+    void process_alignment(const AlnRecord &aln);
+    void flush_batch();
+    void finalize_table();
+    [[noreturn]] void throw_last_error(int status);
+};
+
+}  // namespace ipxhost
+#endif

@@ -1,0 +1,83 @@
+"""GPU: the intronProspector-compatible command line of the product, byte for byte
+against the reference's golden outputs (same rules as tests/test_oracle_golden.py)."""
+import os
+import subprocess
+
+import pytest
+
+from tests import bamio
+from tests.test_oracle_golden import RULES
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "intronprospector_amd", "bin", "intronProspector")
+
+
+@pytest.fixture(scope="session")
+def cli():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "intronprospector_amd", "host")], check=True,
+                   stdout=subprocess.DEVNULL)
+    return CLI
+
+
+def _run(cli, golden, name, outdir, inputs=None):
+    opts, rule_inputs, extra, err_golden = RULES[name]
+    gin = os.path.join(golden, "input")
+    cmd = [cli] + [o.format(G=gin) for o in opts]
+    outs = {"--junction-bed": "juncs.bed", "--intron-bed": "introns.bed", "--intron-calls": "introns.tsv"}
+    outs.update({k: v for k, v in extra.items() if k != "--debug-trace"})
+    for opt, suf in outs.items():
+        cmd.append("%s=%s" % (opt, os.path.join(outdir, "%s.%s" % (name, suf))))
+    cmd += inputs if inputs else [os.path.join(gin, i) for i in rule_inputs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    for suf in outs.values():
+        with open(os.path.join(golden, "expected", "%s.%s" % (name, suf)), "rb") as f:
+            exp = f.read()
+        with open(os.path.join(outdir, "%s.%s" % (name, suf)), "rb") as f:
+            assert f.read() == exp, "%s.%s differs from the reference's golden file" % (name, suf)
+    if err_golden:
+        with open(os.path.join(golden, "expected", err_golden), "rb") as f:
+            assert r.stdout == f.read()
+
+
+@pytest.mark.parametrize("name", sorted(RULES))
+def test_cli_reproduces_reference_golden(cli, golden, tmp_path, name):
+    _run(cli, golden, name, str(tmp_path))
+
+
+@pytest.mark.parametrize("name", ["testBasic3", "testBasic4", "testBasic5"])
+def test_cli_bam_input(cli, golden, tmp_path, name):
+    """the reference runs these rules on a BAM made from test_basic.sam"""
+    bam = str(tmp_path / "test_basic.bam")
+    bamio.sam_to_bam(os.path.join(golden, "input", "test_basic.sam"), bam)
+    _run(cli, golden, name, str(tmp_path), inputs=[bam])
+
+
+def test_cli_gzip_outputs(cli, golden, tmp_path):
+    import gzip
+    out = {s: str(tmp_path / ("b1." + s + ".gz")) for s in ("juncs.bed", "introns.bed", "introns.tsv")}
+    subprocess.run([cli, "--min-confidence-score=0.0", "--junction-bed=" + out["juncs.bed"],
+                    "--intron-bed=" + out["introns.bed"], "--intron-calls=" + out["introns.tsv"],
+                    os.path.join(golden, "input", "test_basic.sam")], check=True)
+    for suf, path in out.items():
+        with open(os.path.join(golden, "expected", "testBasic1." + suf), "rb") as f:
+            assert gzip.open(path, "rb").read() == f.read()
+
+
+def test_cli_out_of_order_targets_error(cli, golden):
+    r = subprocess.run([cli, "--allow-anchor-indels", os.path.join(golden, "input", "ont-out-of-order-targets.sam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 1
+    with open(os.path.join(golden, "expected", "testOntOutOfOrderTargets.err"), "rb") as f:
+        assert r.stdout == f.read()
+
+
+def test_cli_unknown_cigar_op_error(cli, tmp_path):
+    sam = tmp_path / "p.sam"
+    sam.write_text("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:1000000\n"
+                   "r0\t0\tchr1\t100\t60\t20M100N20M\t*\t0\t0\t*\t*\n"
+                   "r1\t0\tchr1\t1001\t60\t10M5P100N10M\t*\t0\t0\t*\t*\n")
+    r = subprocess.run([cli, "--intron-calls=/dev/stdout", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1
+    assert r.stderr.decode() == "Error: Unknown cigar operation 'P'\nUse --help to get usage\n"

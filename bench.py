@@ -37,12 +37,12 @@ def make_workload(kind, reads, seed):
 # n alignments, w CIGAR words, r records
 KERNEL_BYTES = {
     "k_scan": lambda n, w, r: 20 * n + 4 * w + 32 * r,     # SoA + CIGAR in, 32-byte records out
-    "k_hist": lambda n, w, r: 16 * r,                       # one read of the 16-byte sort items
-    "k_scatter": lambda n, w, r: 32 * r,                    # items in, items out
+    "k_hist": lambda n, w, r: 1 * r,                        # one digit byte per record
+    "k_scatter": lambda n, w, r: 33 * r,                    # item in, item + next digit byte out
     "k_count_heads": lambda n, w, r: 16 * r,
     "k_write_heads": lambda n, w, r: 16 * r,
-    "k_phase_a": lambda n, w, r: 32 * r,                    # item + payload of every record
-    "k_phase_b": lambda n, w, r: 32 * r,
+    "k_reduce_a": lambda n, w, r: 32 * r,                   # item + payload of every record
+    "k_reduce": lambda n, w, r: 32 * r,
 }
 
 

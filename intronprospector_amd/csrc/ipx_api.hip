@@ -98,10 +98,12 @@ struct ipx_handle {
     std::vector<int64_t> glen;
     DevBuf d_twobit, d_mask, d_seq_len, d_seq_word2, d_seq_wordm, d_seq_of_rank;
     // records
-    DevBuf items_a, items_b, pays;
+    DevBuf items_a, items_b, pays, dig_a, dig_b;
+    uint32_t key_or[3] = {0, 0, 0}, key_and[3] = {~0u, ~0u, ~0u};   // host copy of Counters::key_or/and
     uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
     uint64_t seen_words = 0, seen_records = 0;     // for the capacity estimate
     uint64_t reserved_records = 0;
+    bool digs_stale = false;     // dig_a no longer holds digit 0 of items_a (after a sort)
     DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2;
     // pinned host
     void *pin_small = nullptr;     // 256 bytes of read-back scalars
@@ -228,6 +230,7 @@ int reset_counters(ipx_handle *h) {
     Counters c{};
     c.n_records = h->n_records;
     c.err_word = IPX_ERRW_NONE;
+    for (int k = 0; k < 3; ++k) { c.key_or[k] = 0; c.key_and[k] = ~0u; h->key_or[k] = 0; h->key_and[k] = ~0u; }
     HIPCHK(hipMemcpyAsync(h->counters.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return IPX_OK;
@@ -239,7 +242,8 @@ int grow_records(ipx_handle *h, uint64_t cap) {
     int rc;
     if ((rc = ensure(h, h->items_a, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
     if ((rc = ensure(h, h->pays, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
-    h->rec_cap = std::min(h->items_a.cap, h->pays.cap) / sizeof(uint4);
+    if ((rc = ensure(h, h->dig_a, cap + 64, true, h->n_records))) return rc;
+    h->rec_cap = std::min(std::min(h->items_a.cap, h->pays.cap) / sizeof(uint4), h->dig_a.cap - 64);
     return IPX_OK;
 }
 
@@ -312,7 +316,7 @@ int ipx_destroy(ipx_handle *h) {
     (void)hipSetDevice(h->params.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
-                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays,
+                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->pass_skip, &h->scratch, &h->out_arena,
                       &h->rank_skip, &h->d_small, &h->out_arena2})
         release(*b);
@@ -391,6 +395,7 @@ int ipx_reserve(ipx_handle *h, uint64_t n_alignments, uint64_t n_cigar_words, ui
     h->reserved_records = n_records;
     if ((rc = grow_records(h, h->n_records + n_records))) return rc;
     if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
     if ((rc = ensure(h, h->sort_ws, ipx_sort_workspace_bytes(h->rec_cap)))) return rc;
     return IPX_OK;
 }
@@ -453,13 +458,14 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
         ipx_prof_mark(h->stream, IPXK_BEGIN);
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                               h->pays.as<uint4>(), h->rec_cap, h->counters.as<Counters>()));
+                               h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
         if (c->n_records <= h->rec_cap) {
+            for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->seen_words += nw;
             h->seen_records += c->n_records - h->n_records;
             h->n_records = c->n_records;
@@ -485,6 +491,7 @@ int ipx_clear(ipx_handle *h) {
     (void)hipSetDevice(h->params.device);
     h->n_records = 0;
     h->n_alignments = 0;
+    h->digs_stale = false;
     memset(&h->table, 0, sizeof h->table);
     return reset_counters(h);
 }
@@ -528,13 +535,29 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         const uint64_t sums1 = ipx_div_up(chunks, 4096) + 2;
         const size_t ws_bytes = std::max(ipx_sort_workspace_bytes(R),
                                          (size_t)((2 * chunks_al + sums1) * sizeof(uint32_t) + 1024));
+        // digits on which the keys differ (OR ^ AND); digit 0 always runs: its bytes come with the records
+        SortPlan plan{};
+        plan.digits[plan.n++] = 0;
+        for (uint32_t d = 1; d < h->key.n_digits; ++d) {
+            const uint32_t w = d >> 2, sh = (d & 3u) * 8u;
+            if (((h->key_or[w] ^ h->key_and[w]) >> sh) & 0xffu) plan.digits[plan.n++] = d;
+        }
         if (resort) {
             if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
+            if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
             if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
-            HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), R, h->key.n_digits,
-                                   h->sort_ws.p, h->sort_ws.cap, h->pass_skip.as<uint32_t>()));
+            HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
+                                   h->dig_b.as<uint8_t>(), !h->digs_stale, R, plan, h->sort_ws.p, h->sort_ws.cap));
+            // the records now live (sorted) in one of the two buffers; keep that one as items_a
+            // so that later pushes append to, and later sorts start from, a full copy
+            if (plan.n & 1u) {
+                std::swap(h->items_a, h->items_b);
+                std::swap(h->dig_a, h->dig_b);
+            }
+            // digit-0 bytes of the sorted order (a later re-sort starts with digit 0 again)
+            h->digs_stale = true;
         }
-        SortedItems si{h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->pass_skip.as<uint32_t>(), h->key.n_digits, R};
+        SortedItems si{h->items_a.as<uint4>(), R};
         uint32_t *chunk_j = h->sort_ws.as<uint32_t>();
         uint32_t *chunk_b = chunk_j + chunks_al;
         uint32_t *sums = chunk_b + chunks_al;
@@ -607,10 +630,11 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         err_word = ((const Counters *)(small + 4))->err_word;
         // ijunc: rank of the creation order (junctions_extractor.cc:459-460)
         if (n_valid) {
-            HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, n_valid, 7, rank_ws, ipx_sort_workspace_bytes(J),
-                                   h->rank_skip.as<uint32_t>()));
-            HIPCHK(ipx_launch_emit_ijunc(s, n_valid, rb.rank_a, rb.rank_b, h->rank_skip.as<uint32_t>(), 7,
-                                         rb.out_ijunc));
+            SortPlan rp{};
+            for (uint32_t d = 0; d < 7; ++d) rp.digits[rp.n++] = d;      // 54-bit creation order
+            HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
+                                   ipx_sort_workspace_bytes(J)));
+            HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));
         }
         if (err_word != IPX_ERRW_NONE && ((err_word >> 8) & 3u) == IPX_ERRK_GENOME) {
             HIPCHK(hipMemsetAsync(detail4, 0, 16, s));
@@ -748,8 +772,8 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
 }
 
 static const char *const kKernelNames[IPXK_COUNT] = {
-    "begin", "k_scan", "k_hist", "sort_hist_scan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
-    "k_write_heads", "k_motif", "memset", "k_phase_a", "k_phase_b", "k_finish_junctions", "k_bins",
+    "begin", "k_scan", "k_hist", "k_binscan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
+    "k_write_heads", "k_motif", "memset", "k_reduce_a", "k_reduce", "k_finish_junctions", "k_bins",
     "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy"};
 
 int ipx_profile(ipx_handle *h, int enable) {

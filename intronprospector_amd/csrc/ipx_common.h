@@ -65,7 +65,14 @@ struct ScanParams {
 struct Counters {
     unsigned long long n_records;      // allocated so far (may exceed capacity)
     unsigned long long err_word;       // earliest data error, IPX_ERRW_NONE if none
-    unsigned long long n_reads_scanned;
+    uint32_t key_or[3], key_and[3];    // OR / AND of all sort keys: bits that never vary need no pass
+    uint32_t pad[2];
+};
+
+// digits (8-bit, least significant first) a sort has to process
+struct SortPlan {
+    uint32_t digits[12];
+    uint32_t n;
 };
 
 struct GenomeDev {
@@ -94,13 +101,15 @@ void ipx_prof_mark(hipStream_t s, int id);
 // ---- launchers implemented in the kernel translation units -------------------
 // ipx_scan.hip
 hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
-                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays,
+                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
                            uint64_t capacity, Counters *counters);
 
 // ipx_sort.hip
 size_t ipx_sort_workspace_bytes(uint64_t n);
-hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint64_t n, uint32_t n_digits,
-                           void *workspace, size_t workspace_bytes, uint32_t *pass_skip /* dev, 16 words */);
+// result in buf_b when plan.n is odd, else in buf_a; dig_a/dig_b: digit-byte streams or NULL
+hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b,
+                           bool first_bytes_valid, uint64_t n, const SortPlan &plan, void *workspace,
+                           size_t workspace_bytes);
 // in == out allowed; block_sums needs div_up(n,4096)+1 words; total may be NULL
 hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
                                uint32_t *block_sums, uint32_t *total);

@@ -3,9 +3,7 @@
 #include "ipx_common.h"
 
 struct SortedItems {
-    const uint4 *a, *b;           // ping-pong buffers of the radix sort
-    const uint32_t *pass_skip;    // device: which passes were dropped -> which buffer holds the result
-    uint32_t n_digits;
+    const uint4 *items;           // records sorted by key
     uint64_t n;
 };
 
@@ -37,8 +35,7 @@ hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t
 hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const KeyLayout &kl,
                              const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters);
-hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *a, const uint4 *b,
-                                 const uint32_t *pass_skip, uint32_t n_digits, uint32_t *ijunc);
+hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *sorted_rank_items, uint32_t *ijunc);
 hipError_t ipx_launch_find_genome_error(hipStream_t s, uint32_t n_j, const unsigned long long *first,
                                         const uint32_t *jmotif, const uint32_t *jrank,
                                         const uint32_t *jstart, const uint32_t *jend,

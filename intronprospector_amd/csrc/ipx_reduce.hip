@@ -31,13 +31,6 @@ constexpr uint32_t CHUNK = 512;
 constexpr uint32_t ROUNDS = CHUNK / 64;
 constexpr unsigned long long NONE64 = 0xffffffffffffffffull;
 
-__device__ __forceinline__ const uint4 *sorted_buf(const uint4 *a, const uint4 *b,
-                                                   const uint32_t *pass_skip, uint32_t n_digits) {
-    uint32_t par = 0;
-    for (uint32_t k = 0; k < n_digits; ++k) par ^= (pass_skip[k] ? 0u : 1u);
-    return par ? b : a;
-}
-
 struct Heads {
     bool ok, head_j, head_b;
     uint4 it;
@@ -62,11 +55,9 @@ __device__ __forceinline__ Heads load_heads(const uint4 *__restrict__ items, uin
     return h;
 }
 
-__global__ __launch_bounds__(256) void k_count_heads(const uint4 *a, const uint4 *b,
-                                                     const uint32_t *pass_skip, uint32_t n_digits,
+__global__ __launch_bounds__(256) void k_count_heads(const uint4 *__restrict__ items,
                                                      uint64_t n, uint32_t *__restrict__ chunk_j,
                                                      uint32_t *__restrict__ chunk_b) {
-    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t base = chunk * CHUNK;
@@ -100,8 +91,7 @@ __device__ __forceinline__ KeyParts unpack_key(const uint4 &it, const KeyLayout 
 }
 
 // junction / bin descriptors at the segment heads
-__global__ __launch_bounds__(256) void k_write_heads(const uint4 *a, const uint4 *b,
-                                                     const uint32_t *pass_skip, uint32_t n_digits,
+__global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ items,
                                                      uint64_t n, KeyLayout kl,
                                                      const uint32_t *__restrict__ chunk_j,
                                                      const uint32_t *__restrict__ chunk_b,
@@ -110,7 +100,6 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *a, const uint4
                                                      uint32_t *__restrict__ jend,
                                                      uint32_t *__restrict__ bin_j,
                                                      uint32_t *__restrict__ bin_off) {
-    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -223,117 +212,243 @@ struct MinU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { r
 struct MaxU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 struct AddU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
 
-// phase A: first[j] = min order over all records; creator[j] = min over passing
-__global__ __launch_bounds__(256) void k_phase_a(const uint4 *a, const uint4 *b,
-                                                 const uint32_t *pass_skip, uint32_t n_digits,
-                                                 uint64_t n, const uint4 *__restrict__ pays,
-                                                 const uint32_t *__restrict__ chunk_j,
-                                                 const uint32_t *__restrict__ jmotif,
-                                                 int32_t sj_filter,
-                                                 unsigned long long *__restrict__ first,
-                                                 unsigned long long *__restrict__ creator) {
-    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t lane_le = ~0ull >> (63 - lane);
-    const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t base = chunk * CHUNK;
-    if (base >= n) return;
-    uint32_t nj = chunk_j[chunk];
-#pragma unroll 1
-    for (uint32_t r = 0; r < ROUNDS; ++r) {
-        const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
-        const uint64_t mj = __ballot(h.head_j);
-        const uint64_t ok_mask = __ballot(h.ok);
-        if (!ok_mask) break;
-        const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
-        nj += (uint32_t)__popcll(mj);
-        unsigned long long ord = NONE64, ordp = NONE64;
-        if (h.ok) {
-            const uint4 p = pays[h.it.w];
-            ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
-            ordp = record_passes(IPX_ORD_STRAND(ord), jmotif[jid], sj_filter) ? ord : NONE64;
+// ---- the reduce kernel ---------------------------------------------------------------
+// MODE 0  no record can fail the filter: creator = first = min order, everything counted
+//         (one pass: phases A and B fused)
+// MODE 1  phase A with an active filter: first[j], creator[j] (min over passing records)
+// MODE 2  phase B with an active filter: tallies over records with order >= creator[j]
+//
+// A wave walks its 512-record chunk in 8 rounds.  Per round the junction segments (and the
+// (junction, offset) bins) are reduced with wave-segmented shuffles.  A segment that runs
+// on into the next round is CARRIED in wave-uniform registers instead of being flushed,
+// so a junction costs one flush per chunk, not per round (a junction with 10^6 records
+// otherwise serialises ~10^5 same-address atomics).  A segment that begins and ends inside
+// the chunk is flushed with plain stores: no other wave ever touches its row.  Only
+// segments that cross a chunk boundary use atomics (rows are pre-set to the identity).
+struct JAcc {
+    unsigned long long m1, m2;      // min order over all / over passing records
+    uint32_t c0, c1, c2, lo, hi;    // counts by category, min anchor_start, max anchor_end
+};
+
+template <int MODE>
+__device__ __forceinline__ void flush_junction(bool plain, uint32_t jid, const JAcc &a,
+                                               unsigned long long *__restrict__ first,
+                                               unsigned long long *__restrict__ creator,
+                                               unsigned long long *__restrict__ counts,
+                                               uint32_t *__restrict__ amin, uint32_t *__restrict__ amax) {
+    if (MODE == 0 || MODE == 1) {
+        if (plain) {
+            first[jid] = a.m1;
+            creator[jid] = a.m2;
+        } else {
+            atomicMin(&first[jid], a.m1);
+            if (a.m2 != NONE64) atomicMin(&creator[jid], a.m2);
         }
-        // lanes past the end form their own segment; lane 0 always starts one
-        const uint64_t heads = mj | 1ull | (~ok_mask & (ok_mask << 1));
-        const uint32_t last = seg_last_lane(heads, lane);
-        const unsigned long long m_all = seg_reduce(ord, lane, last, MinU64());
-        const unsigned long long m_pass = seg_reduce(ordp, lane, last, MinU64());
-        if (h.ok && ((heads >> lane) & 1ull)) {
-            atomicMin(&first[jid], m_all);
-            if (m_pass != NONE64) atomicMin(&creator[jid], m_pass);
+    }
+    if (MODE == 0 || MODE == 2) {
+        if (plain) {
+            counts[(uint64_t)jid * 3 + 0] = a.c0;
+            counts[(uint64_t)jid * 3 + 1] = a.c1;
+            counts[(uint64_t)jid * 3 + 2] = a.c2;
+            amin[jid] = a.lo;
+            amax[jid] = a.hi;
+        } else if ((a.c0 | a.c1 | a.c2) || a.lo != 0xffffffffu) {
+            if (a.c0) atomicAdd(&counts[(uint64_t)jid * 3 + 0], (unsigned long long)a.c0);
+            if (a.c1) atomicAdd(&counts[(uint64_t)jid * 3 + 1], (unsigned long long)a.c1);
+            if (a.c2) atomicAdd(&counts[(uint64_t)jid * 3 + 2], (unsigned long long)a.c2);
+            atomicMin(&amin[jid], a.lo);
+            atomicMax(&amax[jid], a.hi);
         }
     }
 }
 
-// phase B: tallies over the counted records
-__global__ __launch_bounds__(256) void k_phase_b(const uint4 *a, const uint4 *b,
-                                                 const uint32_t *pass_skip, uint32_t n_digits,
-                                                 uint64_t n, const uint4 *__restrict__ pays,
-                                                 const uint32_t *__restrict__ chunk_j,
-                                                 const uint32_t *__restrict__ chunk_b,
-                                                 const unsigned long long *__restrict__ creator,
-                                                 unsigned long long *__restrict__ counts,   // 3 per junction
-                                                 uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
-                                                 uint32_t *__restrict__ bin_count,
-                                                 Counters *counters) {
-    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
+__device__ __forceinline__ JAcc merge_acc(const JAcc &x, const JAcc &y) {
+    JAcc r;
+    r.m1 = x.m1 < y.m1 ? x.m1 : y.m1;
+    r.m2 = x.m2 < y.m2 ? x.m2 : y.m2;
+    r.c0 = x.c0 + y.c0; r.c1 = x.c1 + y.c1; r.c2 = x.c2 + y.c2;
+    r.lo = x.lo < y.lo ? x.lo : y.lo;
+    r.hi = x.hi > y.hi ? x.hi : y.hi;
+    return r;
+}
+
+__device__ __forceinline__ JAcc bcast_acc(const JAcc &x, int src) {
+    JAcc r;
+    r.m1 = __shfl(x.m1, src); r.m2 = __shfl(x.m2, src);
+    r.c0 = __shfl(x.c0, src); r.c1 = __shfl(x.c1, src); r.c2 = __shfl(x.c2, src);
+    r.lo = __shfl(x.lo, src); r.hi = __shfl(x.hi, src);
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
+                                                const uint4 *__restrict__ pays,
+                                                const uint32_t *__restrict__ chunk_j,
+                                                const uint32_t *__restrict__ chunk_b,
+                                                const uint32_t *__restrict__ jmotif, int32_t sj_filter,
+                                                unsigned long long *__restrict__ first,
+                                                unsigned long long *__restrict__ creator,
+                                                unsigned long long *__restrict__ counts,
+                                                uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
+                                                uint32_t *__restrict__ bin_count, Counters *counters) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t base = chunk * CHUNK;
     if (base >= n) return;
-    uint32_t nj = chunk_j[chunk], nb = chunk_b[chunk];
+    uint32_t nj = chunk_j[chunk], nb = (MODE != 1) ? chunk_b[chunk] : 0;
+
+    // carried (unfinished) junction segment and bin; wave-uniform
+    bool cj_valid = false, cj_here = false;
+    uint32_t cj_id = 0;
+    JAcc cj{NONE64, NONE64, 0, 0, 0, 0xffffffffu, 0};
+    bool cb_valid = false, cb_here = false;
+    uint32_t cb_id = 0, cb_cnt = 0;
+    uint4 last_item = make_uint4(0, 0, 0, 0);
+    uint64_t last_index = base;
+
 #pragma unroll 1
     for (uint32_t r = 0; r < ROUNDS; ++r) {
-        const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
-        const uint64_t mj = __ballot(h.head_j), mb = __ballot(h.head_b);
+        const uint64_t i = base + r * 64 + lane;
+        const Heads h = load_heads(items, i, n, lane);
         const uint64_t ok_mask = __ballot(h.ok);
         if (!ok_mask) break;
+        const uint64_t mj = __ballot(h.head_j), mb = __ballot(h.head_b);
         const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
         const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
         nj += (uint32_t)__popcll(mj);
         nb += (uint32_t)__popcll(mb);
-        uint32_t counted = 0, cpk = 0, lo = 0xffffffffu, hi = 0;
+        const int n_ok = __popcll(ok_mask);                 // valid lanes are 0..n_ok-1
+        last_item = make_uint4(__shfl(h.it.x, n_ok - 1), __shfl(h.it.y, n_ok - 1), __shfl(h.it.z, n_ok - 1), 0);
+        last_index = base + r * 64 + (uint64_t)(n_ok - 1);
+
+        JAcc v{NONE64, NONE64, 0, 0, 0, 0xffffffffu, 0};
+        uint32_t counted = 0;
         unsigned long long poison = NONE64;
         if (h.ok) {
             const uint4 p = pays[h.it.w];
             const unsigned long long ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
-            const unsigned long long cr = creator[jid];
-            if (cr != NONE64 && IPX_ORD_SEQ(ord) >= IPX_ORD_SEQ(cr)) {
+            bool cnt_it = true;
+            if (MODE == 1) {
+                v.m1 = ord;
+                v.m2 = record_passes(IPX_ORD_STRAND(ord), jmotif[jid], sj_filter) ? ord : NONE64;
+                cnt_it = false;
+            } else if (MODE == 2) {
+                const unsigned long long cr = creator[jid];
+                cnt_it = (cr != NONE64) && IPX_ORD_SEQ(ord) >= IPX_ORD_SEQ(cr);
+            } else {
+                v.m1 = ord;
+                v.m2 = ord;
+            }
+            if (cnt_it) {
                 counted = 1;
                 const uint32_t cat = IPX_ORD_CAT(ord);
-                if (cat == 3) {     // get_read_category throws, junctions_extractor.cc:73-74
-                    poison = (ord & ~0x3ffull) | (IPX_ERRK_CATEGORY << 8);
-                } else {
-                    cpk = 1u << (cat * 8);
-                }
-                lo = p.z;
-                hi = p.w;
+                if (cat == 3) poison = (ord & ~0x3ffull) | (IPX_ERRK_CATEGORY << 8);   // junctions_extractor.cc:73-74
+                v.c0 = cat == 0; v.c1 = cat == 1; v.c2 = cat == 2;
+                v.lo = p.z;
+                v.hi = p.w;
             }
         }
+        // lanes past the end form their own segment; lane 0 always opens one
         const uint64_t tail = ~ok_mask & (ok_mask << 1);
-        const uint64_t heads_j = mj | 1ull | tail, heads_b = mb | 1ull | tail;
-        const uint32_t last_j = seg_last_lane(heads_j, lane), last_b = seg_last_lane(heads_b, lane);
-        const uint32_t s_cpk = seg_reduce(cpk, lane, last_j, AddU32());
-        const uint32_t s_lo = seg_reduce(lo, lane, last_j, MinU32());
-        const uint32_t s_hi = seg_reduce(hi, lane, last_j, MaxU32());
-        const uint32_t s_bin = seg_reduce(counted, lane, last_b, AddU32());
-        if (h.ok && ((heads_j >> lane) & 1ull) && (s_cpk | (s_lo != 0xffffffffu))) {
-            const uint32_t c0 = s_cpk & 0xffu, c1 = (s_cpk >> 8) & 0xffu, c2 = (s_cpk >> 16) & 0xffu;
-            if (c0) atomicAdd(&counts[(uint64_t)jid * 3 + 0], (unsigned long long)c0);
-            if (c1) atomicAdd(&counts[(uint64_t)jid * 3 + 1], (unsigned long long)c1);
-            if (c2) atomicAdd(&counts[(uint64_t)jid * 3 + 2], (unsigned long long)c2);
-            atomicMin(&amin[jid], s_lo);
-            atomicMax(&amax[jid], s_hi);
+        const uint64_t heads_j = mj | 1ull | tail;
+        const uint32_t last_j = seg_last_lane(heads_j, lane);
+        if (MODE != 2) {
+            v.m1 = seg_reduce(v.m1, lane, last_j, MinU64());
+            v.m2 = seg_reduce(v.m2, lane, last_j, MinU64());
         }
-        if (h.ok && ((heads_b >> lane) & 1ull) && s_bin) atomicAdd(&bin_count[bid], s_bin);
-        // rare: a counted record whose category lookup throws
-        unsigned long long e = poison;
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(e, d);
-            e = o < e ? o : e;
+        if (MODE != 1) {
+            uint32_t cpk = v.c0 | (v.c1 << 8) | (v.c2 << 16);          // <= 64 per field and round
+            cpk = seg_reduce(cpk, lane, last_j, AddU32());
+            v.c0 = cpk & 0xffu; v.c1 = (cpk >> 8) & 0xffu; v.c2 = (cpk >> 16) & 0xffu;
+            v.lo = seg_reduce(v.lo, lane, last_j, MinU32());
+            v.hi = seg_reduce(v.hi, lane, last_j, MaxU32());
         }
-        if (lane == 0 && e != NONE64) atomicMin(&counters->err_word, e);
+
+        // ---- junction segments: carry in, flush complete ones, carry out -------------------
+        {
+            const bool cont0 = !(mj & 1ull);                 // lane 0 continues a segment begun earlier
+            const uint32_t jid0 = __shfl(jid, 0);
+            bool here0 = false;                              // did lane 0's segment begin inside this chunk?
+            if (cj_valid) {
+                if (cont0 && cj_id == jid0) {
+                    if (lane == 0) v = merge_acc(v, cj);
+                    here0 = cj_here;
+                } else if (lane == 0) {
+                    flush_junction<MODE>(cj_here, cj_id, cj, first, creator, counts, amin, amax);
+                }
+                cj_valid = false;
+            }
+            const bool is_head = h.ok && ((heads_j >> lane) & 1ull);
+            const bool runs_on = (last_j == 63) && ((ok_mask >> 63) & 1ull);   // may continue in the next round
+            const bool began_here = (lane == 0 && cont0) ? here0 : true;
+            if (is_head && !runs_on) flush_junction<MODE>(began_here, jid, v, first, creator, counts, amin, amax);
+            const uint64_t carry_mask = __ballot(is_head && runs_on);
+            if (carry_mask) {
+                const int src = __ffsll((unsigned long long)carry_mask) - 1;
+                cj = bcast_acc(v, src);
+                cj_id = __shfl(jid, src);
+                cj_here = __shfl((int)began_here, src) != 0;
+                cj_valid = true;
+            }
+        }
+        // ---- bins ---------------------------------------------------------------------------
+        if (MODE != 1) {
+            const uint64_t heads_b = mb | 1ull | tail;
+            const uint32_t last_b = seg_last_lane(heads_b, lane);
+            uint32_t s_bin = seg_reduce(counted, lane, last_b, AddU32());
+            const bool cont0 = !(mb & 1ull);
+            const uint32_t bid0 = __shfl(bid, 0);
+            bool here0 = false;
+            if (cb_valid) {
+                if (cont0 && cb_id == bid0) {
+                    if (lane == 0) s_bin += cb_cnt;
+                    here0 = cb_here;
+                } else if (lane == 0) {
+                    if (cb_here) bin_count[cb_id] = cb_cnt;
+                    else if (cb_cnt) atomicAdd(&bin_count[cb_id], cb_cnt);
+                }
+                cb_valid = false;
+            }
+            const bool is_head = h.ok && ((heads_b >> lane) & 1ull);
+            const bool runs_on = (last_b == 63) && ((ok_mask >> 63) & 1ull);
+            const bool began_here = (lane == 0 && cont0) ? here0 : true;
+            if (is_head && !runs_on) {
+                if (began_here) bin_count[bid] = s_bin;
+                else if (s_bin) atomicAdd(&bin_count[bid], s_bin);
+            }
+            const uint64_t carry_mask = __ballot(is_head && runs_on);
+            if (carry_mask) {
+                const int src = __ffsll((unsigned long long)carry_mask) - 1;
+                cb_cnt = __shfl(s_bin, src);
+                cb_id = __shfl(bid, src);
+                cb_here = __shfl((int)began_here, src) != 0;
+                cb_valid = true;
+            }
+            // rare: a counted record whose category lookup throws
+            unsigned long long e = poison;
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long o = __shfl_xor(e, d);
+                e = o < e ? o : e;
+            }
+            if (lane == 0 && e != NONE64) atomicMin(&counters->err_word, e);
+        }
+    }
+    // what is still carried ends with the chunk: complete only if the next record has another key
+    if (cj_valid || cb_valid) {
+        bool same_j = false, same_b = false;
+        if (last_index + 1 < n) {
+            const uint4 nx = items[last_index + 1];
+            same_j = ((nx.x >> 16) == (last_item.x >> 16)) && nx.y == last_item.y && nx.z == last_item.z;
+            same_b = same_j && ((nx.x & 0xffffu) == (last_item.x & 0xffffu));
+        }
+        if (lane == 0) {
+            if (cj_valid) flush_junction<MODE>(cj_here && !same_j, cj_id, cj, first, creator, counts, amin, amax);
+            if (MODE != 1 && cb_valid) {
+                if (cb_here && !same_b) bin_count[cb_id] = cb_cnt;
+                else if (cb_cnt) atomicAdd(&bin_count[cb_id], cb_cnt);
+            }
+        }
     }
 }
 
@@ -434,10 +549,8 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     rank_items[o] = make_uint4((uint32_t)seq, (uint32_t)(seq >> 32), 0u, o);
 }
 
-__global__ __launch_bounds__(256) void k_emit_ijunc(uint32_t n, const uint4 *a, const uint4 *b,
-                                                    const uint32_t *pass_skip, uint32_t n_digits,
+__global__ __launch_bounds__(256) void k_emit_ijunc(uint32_t n, const uint4 *__restrict__ items,
                                                     uint32_t *__restrict__ ijunc) {
-    const uint4 *items = sorted_buf(a, b, pass_skip, n_digits);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ijunc[items[i].w] = i;
 }
@@ -468,8 +581,7 @@ uint64_t ipx_reduce_chunks(uint64_t n) { return ipx_div_up(n, CHUNK); }
 
 hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b) {
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
-    hipLaunchKernelGGL(k_count_heads, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
-                       si.n_digits, si.n, chunk_j, chunk_b);
+    hipLaunchKernelGGL(k_count_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, chunk_j, chunk_b);
     ipx_prof_mark(s, IPXK_COUNT_HEADS);
     return hipGetLastError();
 }
@@ -479,8 +591,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters) {
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
     const uint32_t J = rb.n_j, B = rb.n_b;
-    hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
-                       si.n_digits, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
+    hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
                        rb.bin_j, rb.bin_off);
     ipx_prof_mark(s, IPXK_WRITE_HEADS);
     hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
@@ -495,13 +606,20 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     if ((e = hipMemsetAsync(rb.jnb, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.bin_count, 0, sizeof(uint32_t) * B, s)) != hipSuccess) return e;
     ipx_prof_mark(s, IPXK_MEMSET);
-    hipLaunchKernelGGL(k_phase_a, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
-                       si.n_digits, si.n, pays, rb.chunk_j, rb.jmotif, sj_filter, rb.first, rb.creator);
-    ipx_prof_mark(s, IPXK_PHASE_A);
-    hipLaunchKernelGGL(k_phase_b, grid1d(chunks, 4), dim3(256), 0, s, si.a, si.b, si.pass_skip,
-                       si.n_digits, si.n, pays, rb.chunk_j, rb.chunk_b, rb.creator, rb.counts, rb.amin,
-                       rb.amax, rb.bin_count, counters);
-    ipx_prof_mark(s, IPXK_PHASE_B);
+    // A record can fail the filter only against a motif and under "canon" (splice_juncs.cc:52-61)
+    const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
+    if (!filter_active) {
+        hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
+        ipx_prof_mark(s, IPXK_PHASE_B);
+    } else {
+        hipLaunchKernelGGL(k_reduce<1>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
+        ipx_prof_mark(s, IPXK_PHASE_A);
+        hipLaunchKernelGGL(k_reduce<2>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
+        ipx_prof_mark(s, IPXK_PHASE_B);
+    }
     hipLaunchKernelGGL(k_finish_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.first, rb.creator,
                        rb.jmotif, rb.jvalid, rb.jstrand, counters);
     ipx_prof_mark(s, IPXK_FINISH_J);
@@ -525,11 +643,9 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     return hipGetLastError();
 }
 
-hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *a, const uint4 *b,
-                                 const uint32_t *pass_skip, uint32_t n_digits, uint32_t *ijunc) {
+hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *__restrict__ items, uint32_t *ijunc) {
     if (n_valid == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_emit_ijunc, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, a, b, pass_skip,
-                       n_digits, ijunc);
+    hipLaunchKernelGGL(k_emit_ijunc, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, items, ijunc);
     ipx_prof_mark(s, IPXK_EMIT_IJUNC);
     return hipGetLastError();
 }

@@ -65,9 +65,11 @@ __device__ __forceinline__ bool qc_pass(const ScanParams &p, const ReadCtx &c, c
            left >= (int64_t)p.min_anchor_length && right >= (int64_t)p.min_anchor_length;
 }
 
+struct KeyBits { uint32_t o0, o1, o2, a0, a1, a2; };
+
 __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx &c, const Rec &r,
                                              uint32_t ordinal, uint64_t idx, uint4 *__restrict__ items,
-                                             uint4 *__restrict__ pays) {
+                                             uint4 *__restrict__ pays, uint8_t *__restrict__ digs, KeyBits &kb) {
     const uint32_t start = (uint32_t)r.intron_start;
     const uint32_t len = (uint32_t)(r.intron_end - r.intron_start);
     const uint32_t off16 = (uint32_t)(r.intron_start - c.pos) & 0xffffu;
@@ -87,6 +89,9 @@ __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx 
     items[idx] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)idx);
     pays[idx] = make_uint4((uint32_t)order, (uint32_t)(order >> 32), (uint32_t)r.anchor_start,
                            (uint32_t)r.anchor_end);
+    digs[idx] = (uint8_t)lo;                       // digit 0 for the first sort pass
+    kb.o0 |= (uint32_t)lo; kb.o1 |= (uint32_t)(lo >> 32); kb.o2 |= (uint32_t)hi;
+    kb.a0 &= (uint32_t)lo; kb.a1 &= (uint32_t)(lo >> 32); kb.a2 &= (uint32_t)hi;
 }
 
 // The reference's ReadJunctionExtractor::parse_read over one CIGAR.  EMIT=false counts
@@ -97,6 +102,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
                                              const uint32_t *__restrict__ cig, uint32_t nc,
                                              uint64_t slot0, uint64_t capacity,
                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                             uint8_t *__restrict__ digs, KeyBits &kb,
                                              unsigned long long &err) {
     uint32_t state = ST_LIMBO;
     int64_t target_pos = c.pos, anchor_start = -1, intron_start = -1, intron_end = -1, anchor_end = -1;
@@ -107,7 +113,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
         if (qc_pass(p, c, r)) {
             if (EMIT) {
                 const uint64_t idx = slot0 + ordinal;
-                if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays);
+                if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
             }
             ++ordinal;
         }
@@ -199,8 +205,11 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
                                               const uint32_t *__restrict__ cigar,
                                               const uint32_t *__restrict__ rank_of_tid,
                                               uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                              uint8_t *__restrict__ digs,
                                               uint64_t capacity, Counters *counters) {
     __shared__ uint32_t wsum[RPT][4];
+    __shared__ uint32_t kb_s[4][6];
+    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
     __shared__ uint32_t cnt_s[RPT][256], base_s[RPT][256];
     __shared__ unsigned long long tile_slot;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
             ReadCtx c;
             uint32_t nc, off;
             load_ctx(i, c, nc, off, my_err);
-            const uint32_t cn = nc ? run_read<false>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, my_err) : 0;
+            const uint32_t cn = nc ? run_read<false>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err) : 0;
             cnt_s[r][t] = cn;
             // inclusive scan inside the wave
             uint32_t v = cn;
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
                     ReadCtx c;
                     uint32_t nc, off;
                     load_ctx(i, c, nc, off, dummy);
-                    (void)run_read<true>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, dummy);
+                    (void)run_read<true>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy);
                 }
             }
         }
@@ -295,27 +304,48 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
         if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
         __syncthreads();          // tile_slot / wsum are reused by the next tile
     }
+    // OR / AND of every key this block stored -> six atomics per block
+    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const uint32_t o = __shfl_xor(v[k], dlt);
+            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
+        }
+        if (lane == 0) kb_s[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (t < 6) {
+        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        if (t < 3) {
+            const uint32_t o = x0 | x1 | x2 | x3;
+            if (o) atomicOr(&counters->key_or[t], o);
+        } else {
+            const uint32_t a = x0 & x1 & x2 & x3;
+            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+        }
+    }
 }
 
 }  // namespace
 
 hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
-                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays,
+                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
                            uint64_t capacity, Counters *counters) {
     if (b.n_alignments == 0) return hipSuccess;
     // short CIGARs: 8 alignments per thread and tile (2048 per atomic); long ones: 1
     const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;
     const uint64_t per_tile = short_reads ? 2048 : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
-    if (blocks > 256ull * 32) blocks = 256ull * 32;
+    if (blocks > 256ull * 8) blocks = 256ull * 8;
     if (short_reads)
         hipLaunchKernelGGL(k_scan<8>, dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, rank_of_tid, items, pays, capacity, counters);
+                           b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
     else
         hipLaunchKernelGGL(k_scan<1>, dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, rank_of_tid, items, pays, capacity, counters);
+                           b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
     ipx_prof_mark(s, IPXK_SCAN);
     return hipGetLastError();
 }

@@ -1,14 +1,25 @@
 // ipx_sort.hip -- LSD radix sort of 16-byte junction-record items, and the
-// exclusive prefix sum it is built on.
+// exclusive prefix sum used around it.
 //
 // No reference counterpart: the reference keeps a std::map<JunctionKey,...>
 // (junctions.hh:225-246); here the map's ordering (junctions.hh:77-100) is
 // produced by sorting the 96-bit keys built in ipx_scan.hip.
 //
-// Per 8-bit digit: k_hist (per-tile digit counts, bin-major) -> exclusive scan
-// -> k_skip (a digit on which every key agrees moves nothing: the pass is
-// dropped on the device, no host round trip) -> k_scatter (stable multi-split,
-// tile reordered in LDS so that each digit's run leaves as one contiguous write).
+// Per 8-bit digit: k_hist (per-tile digit counts, bin-major) -> k_binscan (one block
+// per bin: exclusive prefix over the tiles + bin total) -> k_scatter (stable multi-split;
+// the tile is reordered in LDS so that each digit's run leaves as one contiguous write).
+// Which digits are worth a pass is decided by the caller from the OR/AND of all keys
+// (digits on which every key agrees move nothing).
+//
+// Digit bytes: a histogram needs one byte of each 16-byte item.  k_scatter therefore
+// also writes, next to every item it moves, the byte the NEXT pass will look at (1 B per
+// item), and k_hist reads that byte stream instead of the items: per pass the sort moves
+// 1 + 16 + 16 + 1 bytes per item instead of 16 + 16 + 16.
+//
+// Tried and dropped (round 1): a one-pass-per-digit "onesweep" (fused histogram +
+// decoupled look-back on sc1 status words, in ticketed and in persistent form).  It was
+// correct but ~2x slower per pass than k_scatter here: look-back chains over tiles that
+// run in lockstep cost more than the separate histogram read saves.
 #include "ipx_common.h"
 
 namespace {
@@ -17,64 +28,84 @@ constexpr uint32_t SORT_THREADS = 256;
 constexpr uint32_t SORT_IPT = 8;                        // items per thread
 constexpr uint32_t SORT_TILE = SORT_THREADS * SORT_IPT; // 2048 items = 32 KiB
 constexpr uint32_t SCAN_TILE = 4096;
+constexpr uint32_t NO_DIGIT = 0xffffffffu;
 
 __device__ __forceinline__ uint32_t digit_of(const uint4 &it, uint32_t d) {
     const uint32_t w = (d >> 2) == 0 ? it.x : ((d >> 2) == 1 ? it.y : it.z);
     return (w >> ((d & 3u) * 8u)) & 0xffu;
 }
 
-// which ping-pong buffer holds the data before pass d: parity of performed passes
-__device__ __forceinline__ uint32_t parity_before(const uint32_t *pass_skip, uint32_t d) {
-    uint32_t par = 0;
-    for (uint32_t k = 0; k < d; ++k) par ^= (pass_skip[k] ? 0u : 1u);
-    return par;
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__ a,
-                                                       const uint4 *__restrict__ b, uint64_t n,
-                                                       uint32_t d, const uint32_t *pass_skip,
-                                                       uint32_t *__restrict__ hist, uint32_t n_tiles) {
+// per-tile digit histogram; BYTES: from the digit-byte stream, else from the items
+template <bool BYTES>
+__global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__ items,
+                                                       const uint8_t *__restrict__ digs, uint64_t n,
+                                                       uint32_t d, uint32_t *__restrict__ hist,
+                                                       uint32_t n_tiles) {
     __shared__ uint32_t h[256];
-    const uint4 *src = parity_before(pass_skip, d) ? b : a;
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+    if (BYTES) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * 8;
+        if (i0 + 8 <= n) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(digs + i0);      // tile bases are 2048-aligned
 #pragma unroll
-    for (uint32_t r = 0; r < SORT_IPT; ++r) {
-        const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[digit_of(src[i], d)], 1u);
+            for (uint32_t k = 0; k < 4; ++k) {
+                atomicAdd(&h[(v.x >> (8 * k)) & 0xffu], 1u);
+                atomicAdd(&h[(v.y >> (8 * k)) & 0xffu], 1u);
+            }
+        } else {
+            for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t r = 0; r < SORT_IPT; ++r) {
+            const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[digit_of(items[i], d)], 1u);
+        }
     }
     __syncthreads();
     hist[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// after the exclusive scan of hist: bin b holds all n items  <=>  pass moves nothing
-__global__ void k_skip(const uint32_t *__restrict__ scanned, uint32_t n_tiles, uint64_t n,
-                       uint32_t d, uint32_t *pass_skip) {
-    __shared__ uint32_t any;
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    const uint32_t bin = threadIdx.x;
-    const uint64_t lo = scanned[(uint64_t)bin * n_tiles];
-    const uint64_t hi = (bin == 255) ? n : scanned[(uint64_t)(bin + 1) * n_tiles];
-    if (hi - lo == n) any = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) pass_skip[d] = any;
+// block b: hist[b][0..n_tiles) -> exclusive prefix in place, bin_total[b] = sum
+__global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, uint32_t n_tiles,
+                                                 uint32_t *__restrict__ bin_total) {
+    __shared__ uint32_t ws[4];
+    uint32_t *row = hist + (uint64_t)blockIdx.x * n_tiles;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < n_tiles) ? row[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += x;
+        }
+        __syncthreads();
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < wave; ++w) off += ws[w];
+        if (i < n_tiles) row[i] = carry + off + incl - v;
+        carry += ws[0] + ws[1] + ws[2] + ws[3];
+    }
+    if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *a, const uint4 *b, uint64_t n,
-                                                          uint32_t d, const uint32_t *pass_skip,
-                                                          const uint32_t *__restrict__ scanned,
+template <bool WRITE_NEXT>
+__global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                          uint8_t *__restrict__ dig_dst, uint64_t n, uint32_t d,
+                                                          uint32_t next_d, const uint32_t *__restrict__ scanned,
+                                                          const uint32_t *__restrict__ bin_total,
                                                           uint32_t n_tiles) {
-    if (pass_skip[d]) return;
-    const uint32_t par = parity_before(pass_skip, d);
-    const uint4 *__restrict__ src = par ? b : a;
-    uint4 *__restrict__ dst = par ? const_cast<uint4 *>(a) : const_cast<uint4 *>(b);
-
     __shared__ uint4 tile[SORT_TILE];          // 32 KiB
     __shared__ uint32_t cnt[4][256];           // per-wave digit counts
     __shared__ uint32_t tile_excl[256];        // exclusive digit prefix inside the tile
     __shared__ uint32_t gbase[256];            // global offset of (digit, this tile)
+    __shared__ uint32_t wsum[4], wsum2[4];
 
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -82,8 +113,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *a, const 
     const uint32_t valid = (uint32_t)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
 
     for (uint32_t k = t; k < 4 * 256; k += SORT_THREADS) (&cnt[0][0])[k] = 0;
-    gbase[t] = scanned[(uint64_t)t * n_tiles + blockIdx.x];
-    __syncthreads();
+    // global base of bin t = (items in smaller bins) + (bin-t items in earlier tiles)
+    const uint32_t my_total = bin_total[t];
+    const uint32_t my_before = scanned[(uint64_t)t * n_tiles + blockIdx.x];
+    {
+        uint32_t incl = my_total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += x;
+        }
+        if (lane == 63) wsum2[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < wave; ++w) off += wsum2[w];
+        gbase[t] = off + incl - my_total + my_before;
+    }
 
     // wave w owns tile items [w*512, w*512+512) in 8 rounds of 64: item order is
     // (wave, round, lane), which is memory order -> the split is stable.
@@ -119,16 +164,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *a, const 
     {
         const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
         const uint32_t tot = c0 + c1 + c2 + c3;
-        // turn per-wave counts into per-wave exclusive offsets
         cnt[0][t] = 0; cnt[1][t] = c0; cnt[2][t] = c0 + c1; cnt[3][t] = c0 + c1 + c2;
-        // block exclusive scan of tot over 256 digits
         uint32_t incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o);
             if ((int)lane >= o) incl += v;
         }
-        __shared__ uint32_t wsum[4];
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         uint32_t woff = 0;
@@ -145,14 +187,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *a, const 
     }
     __syncthreads();
 
-    // contiguous runs per digit leave together
+    // contiguous runs per digit leave together; the next pass's digit byte goes along
 #pragma unroll
     for (uint32_t r = 0; r < SORT_IPT; ++r) {
         const uint32_t slot = r * SORT_THREADS + t;
         if (slot < valid) {
             const uint4 v = tile[slot];
             const uint32_t dig = digit_of(v, d);
-            dst[(uint64_t)gbase[dig] + (slot - tile_excl[dig])] = v;
+            const uint64_t pos = (uint64_t)gbase[dig] + (slot - tile_excl[dig]);
+            dst[pos] = v;
+            if (WRITE_NEXT) dig_dst[pos] = (uint8_t)digit_of(v, next_d);
         }
     }
 }
@@ -225,8 +269,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint32_t
 
 }  // namespace
 
-static hipError_t scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
-                           uint32_t *block_sums, uint32_t *total, int prof_id) {
+hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
+                               uint32_t *block_sums, uint32_t *total) {
     if (n == 0) {
         if (total) return hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return hipSuccess;
@@ -235,43 +279,51 @@ static hipError_t scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uin
     hipLaunchKernelGGL(k_scan_sums, dim3((uint32_t)m), dim3(256), 0, s, in, n, block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, m, total);
     hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)m), dim3(256), 0, s, in, out, n, block_sums);
-    ipx_prof_mark(s, prof_id);
+    ipx_prof_mark(s, IPXK_SCAN_U32);
     return hipGetLastError();
 }
 
-hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
-                               uint32_t *block_sums, uint32_t *total) {
-    return scan_u32(s, in, out, n, block_sums, total, IPXK_SCAN_U32);
-}
-
-// workspace: hist[256 * n_tiles] + scan block sums
+// workspace: hist[256 * n_tiles] + bin_total[256]
 size_t ipx_sort_workspace_bytes(uint64_t n) {
     const uint64_t n_tiles = ipx_div_up(n ? n : 1, SORT_TILE);
-    const uint64_t hist = 256 * n_tiles;
-    const uint64_t sums = ipx_div_up(hist, SCAN_TILE) + 1;
-    return (size_t)((hist + sums) * sizeof(uint32_t) + 256);
+    return (size_t)((256 * n_tiles + 256) * sizeof(uint32_t) + 256);
 }
 
-hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint64_t n, uint32_t n_digits,
-                           void *workspace, size_t workspace_bytes, uint32_t *pass_skip) {
-    hipError_t e = hipMemsetAsync(pass_skip, 0, sizeof(uint32_t) * 16, s);
-    if (e != hipSuccess) return e;
-    if (n == 0) return hipSuccess;
+// Sorts by the listed digits, least significant first.  The result is in buf_b when
+// plan.n is odd, in buf_a otherwise.  dig_a (may be NULL) holds the bytes of digit
+// plan.digits[0] for the items in buf_a; dig_b is its ping-pong partner.
+// first_bytes_valid: dig_a really holds digit plan.digits[0] of buf_a (else the first
+// histogram reads the items).
+hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b,
+                           bool first_bytes_valid, uint64_t n, const SortPlan &plan, void *workspace,
+                           size_t workspace_bytes) {
+    if (n == 0 || plan.n == 0) return hipSuccess;
+    if (ipx_sort_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)ipx_div_up(n, SORT_TILE);
     uint32_t *hist = (uint32_t *)workspace;
-    uint32_t *sums = hist + (uint64_t)256 * n_tiles;
-    if (ipx_sort_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
-    for (uint32_t d = 0; d < n_digits; ++d) {
-        hipLaunchKernelGGL(k_hist, dim3(n_tiles), dim3(SORT_THREADS), 0, s, buf_a, buf_b, n, d,
-                           pass_skip, hist, n_tiles);
+    uint32_t *bin_total = hist + (uint64_t)256 * n_tiles;
+    const bool bytes = dig_a != nullptr && dig_b != nullptr;
+    uint4 *src = buf_a, *dst = buf_b;
+    uint8_t *dsrc = dig_a, *ddst = dig_b;
+    for (uint32_t k = 0; k < plan.n; ++k) {
+        const uint32_t d = plan.digits[k];
+        const uint32_t next_d = (k + 1 < plan.n) ? plan.digits[k + 1] : NO_DIGIT;
+        if (bytes && (k > 0 || first_bytes_valid))
+            hipLaunchKernelGGL(k_hist<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
+        else
+            hipLaunchKernelGGL(k_hist<false>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
         ipx_prof_mark(s, IPXK_SORT_HIST);
-        e = scan_u32(s, hist, hist, (uint64_t)256 * n_tiles, sums, nullptr, IPXK_SORT_SCAN);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_skip, dim3(1), dim3(256), 0, s, hist, n_tiles, n, d, pass_skip);
-        ipx_prof_mark(s, IPXK_SORT_SKIP);
-        hipLaunchKernelGGL(k_scatter, dim3(n_tiles), dim3(SORT_THREADS), 0, s, buf_a, buf_b, n, d,
-                           pass_skip, hist, n_tiles);
+        hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
+        ipx_prof_mark(s, IPXK_SORT_SCAN);
+        if (bytes && next_d != NO_DIGIT)
+            hipLaunchKernelGGL(k_scatter<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d, next_d,
+                               hist, bin_total, n_tiles);
+        else
+            hipLaunchKernelGGL(k_scatter<false>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d,
+                               next_d, hist, bin_total, n_tiles);
         ipx_prof_mark(s, IPXK_SORT_SCATTER);
+        uint4 *ti = src; src = dst; dst = ti;
+        uint8_t *tb = dsrc; dsrc = ddst; ddst = tb;
     }
     return hipGetLastError();
 }

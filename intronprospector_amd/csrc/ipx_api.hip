@@ -268,8 +268,10 @@ void fill_data_error(ipx_handle *h, unsigned long long w) {
             break;
         default:
             e.kind = IPX_DATA_TARGET;
-            snprintf(e.detail, sizeof e.detail, detail ? "more than 2^20-1 junction records in one alignment"
-                                                      : "alignment tid is not a valid target index");
+            snprintf(e.detail, sizeof e.detail, "%s",
+                     detail == 1 ? "more than 2^20-1 junction records in one alignment"
+                     : detail == 2 ? "alignment spans 2^32 or more reference bases"
+                                   : "alignment tid is not a valid target index");
             break;
     }
 }
@@ -581,11 +583,11 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             rb.chunk_j = chunk_j; rb.chunk_b = chunk_b; rb.n_j = J; rb.n_b = B;
             rb.jrank = tmp.take<uint32_t>(J); rb.jstart = tmp.take<uint32_t>(J); rb.jend = tmp.take<uint32_t>(J);
             rb.jmotif = tmp.take<uint32_t>(J); rb.amin = tmp.take<uint32_t>(J); rb.amax = tmp.take<uint32_t>(J);
-            rb.jvalid = tmp.take<uint32_t>(J); rb.jpos = tmp.take<uint32_t>(J); rb.jnb = tmp.take<uint32_t>(J);
+            rb.jvalid = tmp.take<uint32_t>(J); rb.jpos = tmp.take<uint32_t>(J); rb.jfirstbin = tmp.take<uint32_t>(J);
             rb.jstrand = tmp.take<uint8_t>(J);
             rb.first = tmp.take<unsigned long long>(J); rb.creator = tmp.take<unsigned long long>(J);
             rb.counts = tmp.take<unsigned long long>(3ull * J);
-            rb.bin_j = tmp.take<uint32_t>(B); rb.bin_off = tmp.take<uint32_t>(B); rb.bin_count = tmp.take<uint32_t>(B);
+            rb.bin_off = tmp.take<uint32_t>(B); rb.bin_count = tmp.take<uint32_t>(B);
             rb.bin_flag = tmp.take<uint32_t>(B); rb.bin_pos = tmp.take<uint32_t>(B);
             rb.scan_sums = tmp.take<uint32_t>(ipx_div_up(std::max<uint64_t>(std::max(J, B), 1), 4096) + 2);
             rb.totals = tmp.take<uint32_t>(64);

@@ -12,11 +12,11 @@ struct ReduceBuffers {
     uint32_t *chunk_j, *chunk_b;
     uint32_t n_j, n_b;            // junction keys / (key, off16) bins before filtering
     // per junction key (n_j)
-    uint32_t *jrank, *jstart, *jend, *jmotif, *amin, *amax, *jvalid, *jpos, *jnb;
+    uint32_t *jrank, *jstart, *jend, *jmotif, *amin, *amax, *jvalid, *jpos, *jfirstbin;
     uint8_t *jstrand;
     unsigned long long *first, *creator, *counts;
     // per bin (n_b)
-    uint32_t *bin_j, *bin_off, *bin_count, *bin_flag, *bin_pos;
+    uint32_t *bin_off, *bin_count, *bin_flag, *bin_pos;
     uint32_t *scan_sums;          // >= div_up(max(n_j, n_b), 4096) + 1
     uint32_t *totals;             // [0] valid junctions, [1] non-empty bins
     // outputs (device), sized n_j / n_b

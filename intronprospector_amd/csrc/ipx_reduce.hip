@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
                                                      uint32_t *__restrict__ jrank,
                                                      uint32_t *__restrict__ jstart,
                                                      uint32_t *__restrict__ jend,
-                                                     uint32_t *__restrict__ bin_j,
+                                                     uint32_t *__restrict__ jfirstbin,
                                                      uint32_t *__restrict__ bin_off) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
@@ -114,9 +114,8 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
         const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
         if (h.head_b) {
             const KeyParts k = unpack_key(h.it, kl);
-            bin_j[bid] = jid;
             bin_off[bid] = k.off16;
-            if (h.head_j) { jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; }
+            if (h.head_j) { jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; jfirstbin[jid] = bid; }
         }
         nj += (uint32_t)__popcll(mj);
         nb += (uint32_t)__popcll(mb);
@@ -483,16 +482,12 @@ __global__ __launch_bounds__(256) void k_finish_junctions(uint32_t n_j,
     jstrand[j] = (uint8_t)s;
 }
 
-// non-empty bins: flag for compaction, and count them per junction
+// non-empty bins: flag for compaction
 __global__ __launch_bounds__(256) void k_bins(uint32_t n_b, const uint32_t *__restrict__ bin_count,
-                                              const uint32_t *__restrict__ bin_j,
-                                              uint32_t *__restrict__ bin_flag,
-                                              uint32_t *__restrict__ jnb) {
+                                              uint32_t *__restrict__ bin_flag) {
     const uint32_t bidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (bidx >= n_b) return;
-    const uint32_t nz = bin_count[bidx] ? 1u : 0u;
-    bin_flag[bidx] = nz;
-    if (nz) atomicAdd(&jnb[bin_j[bidx]], 1u);
+    bin_flag[bidx] = bin_count[bidx] ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_emit_bins(uint32_t n_b, const uint32_t *__restrict__ bin_count,
@@ -524,7 +519,8 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     const uint32_t *__restrict__ jend, const uint32_t *__restrict__ amin,
     const uint32_t *__restrict__ amax, const uint8_t *__restrict__ jstrand,
     const uint32_t *__restrict__ jmotif, const unsigned long long *__restrict__ counts,
-    const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jnb_scan,
+    const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jfirstbin,
+    const uint32_t *__restrict__ bin_pos,
     const uint32_t *__restrict__ tid_of_rank, const uint32_t *n_valid_total,
     const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,7 +539,7 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     out.read_counts[(uint64_t)o * 3 + 2] = counts[(uint64_t)j * 3 + 2];
     const unsigned long long cr = creator[j];
     out.creator_order[o] = IPX_ORD_SEQ(cr);
-    out.hist_begin[o] = jnb_scan[j];
+    out.hist_begin[o] = bin_pos[jfirstbin[j]];      // bins are ordered by (junction, offset)
     // creation order = (read_index, ordinal): sort key for the ijunc ranks
     const unsigned long long seq = IPX_ORD_SEQ(cr);
     rank_items[o] = make_uint4((uint32_t)seq, (uint32_t)(seq >> 32), 0u, o);
@@ -592,7 +588,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
     const uint32_t J = rb.n_j, B = rb.n_b;
     hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
-                       rb.bin_j, rb.bin_off);
+                       rb.jfirstbin, rb.bin_off);
     ipx_prof_mark(s, IPXK_WRITE_HEADS);
     hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
                        rb.jstart, rb.jend, rb.jmotif);
@@ -603,7 +599,6 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     if ((e = hipMemsetAsync(rb.amin, 0xff, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.amax, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.counts, 0, sizeof(uint64_t) * 3 * J, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.jnb, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.bin_count, 0, sizeof(uint32_t) * B, s)) != hipSuccess) return e;
     ipx_prof_mark(s, IPXK_MEMSET);
     // A record can fail the filter only against a motif and under "canon" (splice_juncs.cc:52-61)
@@ -623,13 +618,11 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     hipLaunchKernelGGL(k_finish_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.first, rb.creator,
                        rb.jmotif, rb.jvalid, rb.jstrand, counters);
     ipx_prof_mark(s, IPXK_FINISH_J);
-    hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_j, rb.bin_flag,
-                       rb.jnb);
+    hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_flag);
     ipx_prof_mark(s, IPXK_BINS);
     // compaction offsets: junctions, bins, bins per junction
     if ((e = ipx_launch_scan_u32(s, rb.jvalid, rb.jpos, J, rb.scan_sums, rb.totals + 0)) != hipSuccess) return e;
     if ((e = ipx_launch_scan_u32(s, rb.bin_flag, rb.bin_pos, B, rb.scan_sums, rb.totals + 1)) != hipSuccess) return e;
-    if ((e = ipx_launch_scan_u32(s, rb.jnb, rb.jnb, J, rb.scan_sums, nullptr)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
                        rb.bin_pos, rb.out_hist_value, rb.out_hist_count);
     ipx_prof_mark(s, IPXK_EMIT_BINS);
@@ -638,7 +631,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                 rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
     hipLaunchKernelGGL(k_emit_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
-                       rb.jnb, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a);
+                       rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a);
     ipx_prof_mark(s, IPXK_EMIT_J);
     return hipGetLastError();
 }

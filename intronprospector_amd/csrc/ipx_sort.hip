@@ -49,10 +49,23 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
         const uint64_t i0 = base + (uint64_t)threadIdx.x * 8;
         if (i0 + 8 <= n) {
             const uint2 v = *reinterpret_cast<const uint2 *>(digs + i0);      // tile bases are 2048-aligned
+            // high digits of (nearly) sorted keys: the thread's 8 bytes, often the whole wave's,
+            // are one value -> one LDS add instead of 8 (512) on a single, contended bin
+            const uint32_t b0 = v.x & 0xffu;
+            const bool uni = (v.x == b0 * 0x01010101u) && (v.y == v.x);
+            const uint64_t act = __ballot(1);
+            const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
+            if (__ballot(uni && b0 == first) == act) {
+                if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
+                    atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
+            } else if (uni) {
+                atomicAdd(&h[b0], 8u);
+            } else {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                atomicAdd(&h[(v.x >> (8 * k)) & 0xffu], 1u);
-                atomicAdd(&h[(v.y >> (8 * k)) & 0xffu], 1u);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    atomicAdd(&h[(v.x >> (8 * k)) & 0xffu], 1u);
+                    atomicAdd(&h[(v.y >> (8 * k)) & 0xffu], 1u);
+                }
             }
         } else {
             for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
@@ -75,10 +88,13 @@ __global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, ui
     uint32_t *row = hist + (uint64_t)blockIdx.x * n_tiles;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < n_tiles) ? row[i] : 0;
-        uint32_t incl = v;
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) v[k] = (i + k < n_tiles) ? row[i + k] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t x = __shfl_up(incl, o);
@@ -87,9 +103,13 @@ __global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, ui
         __syncthreads();
         if (lane == 63) ws[wave] = incl;
         __syncthreads();
-        uint32_t off = 0;
+        uint32_t off = carry + incl - mine;
         for (uint32_t w = 0; w < wave; ++w) off += ws[w];
-        if (i < n_tiles) row[i] = carry + off + incl - v;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (i + k < n_tiles) row[i + k] = off;
+            off += v[k];
+        }
         carry += ws[0] + ws[1] + ws[2] + ws[3];
     }
     if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;

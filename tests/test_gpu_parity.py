@@ -72,6 +72,33 @@ def test_short_reads_multiple_pushes_equal_single():
     helpers.compare_tables(dev, ora)
 
 
+def test_finalize_then_push_more_then_finalize_again():
+    """The table may be asked for repeatedly while records accumulate (multi-input mode of the
+    host): a second sort starts from an already permuted record array."""
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(50_000, seed=17, n_targets=3, target_len=4_000_000, n_sites=1200)
+    ex = _extractor(targets=names)
+    half = len(batch["tid"]) // 2
+    ex.push(synth.slice_batch(batch, 0, half))
+    first = ex.get_junctions()
+    again = ex.get_junctions()
+    for k in ("intron_start", "intron_end", "anchor_start", "anchor_end", "ijunc", "counts", "hist_count"):
+        assert np.array_equal(first[k], again[k])
+    ex.push(synth.slice_batch(batch, half, len(batch["tid"])))
+    dev = ex.get_junctions()
+    ex.close()
+    # (one oracle per comparison: like the reference, it caches a junction's confidence and
+    # sorted offsets the first time they are asked for)
+    ora = Oracle(targets=names)
+    ora.process(synth.slice_batch(batch, 0, half))
+    helpers.compare_tables(first, ora.table())
+    ora.close()
+    ora = Oracle(targets=names)
+    ora.process(batch)
+    helpers.compare_tables(dev, ora.table())
+    ora.close()
+
+
 @pytest.mark.parametrize("flt", [0, 1, 2])
 def test_genome_filter_strand_motif(tmp_path, flt):
     """config G: device 2-bit genome, canonical filter, fail-then-pass ordering."""

@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10M for S, 200k for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi", default="exchange", choices=["exchange", "tables"],
+                    help="N>1: exchange junction records by key range (default) or merge shard tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a one-GPU box (tables merged on the CPU)")
     args = ap.parse_args()
@@ -120,9 +122,14 @@ def main():
     ex.reserve(0, 0, n_words // 2 + 1024)
 
     merger = None
+    exchanger = None
     if world > 1:
         from intronprospector_amd import distributed
-        merger = distributed.TableMerger(dev if args.backend == "nccl" else torch.device("cpu"))
+        comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
+        if args.multi == "tables":
+            merger = distributed.TableMerger(comm_dev)
+        else:
+            exchanger = distributed.RecordExchanger(dev, comm_device=comm_dev)
 
     n_records = [0]
     n_merged = [0]
@@ -130,6 +137,14 @@ def main():
     def step():
         ex.clear()
         ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
+        if exchanger is not None:
+            # junction records -> key-range owners over RCCL (all_to_all), then the local finalize
+            table, ijunc = exchanger.run(ex, n)
+            n_records[0] = table.n_records
+            tot = torch.tensor([int(table.n_junctions)], dtype=torch.int64, device=comm_dev)
+            dist.all_reduce(tot)
+            n_merged[0] = int(tot.item())
+            return table
         if merger is not None:
             # partial tables of this rank's shard -> RCCL merge of the junction tables
             merged, table = merger.merge(ex, rank * n)

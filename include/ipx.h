@@ -230,6 +230,24 @@ int ipx_last_error(const ipx_handle *h, ipx_error *out);
  * that shard its from_creator row, later shards their out_all row. */
 int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creator, ipx_table *out_all);
 
+/* Record exchange (the faster multi-GPU path when tables are not much smaller than the
+ * records): every rank splits its pending records at the same splitters on the partition
+ * key (chromosome rank << 32 | intron start; all records of a junction share it), the
+ * caller exchanges the parts with one all_to_all over RCCL, each rank adopts what it
+ * received and calls ipx_finalize on the key range it now owns.  Records carry their
+ * global order, so the result does not depend on arrival order.
+ *   ipx_records_sample     partition keys of n_samples (<= 4096) evenly spaced pending records
+ *   ipx_records_partition  n_parts (<= 64) parts: part p holds the keys in
+ *                          [splitters[p-1], splitters[p]); counts[p] records each; the
+ *                          32-byte records are written part after part to dst_records
+ *                          (device memory, room for ipx_records_pending records)
+ *   ipx_records_adopt      replaces the handle's pending records by n received ones */
+int ipx_records_pending(const ipx_handle *h, uint64_t *n_records);
+int ipx_records_sample(ipx_handle *h, uint32_t n_samples, uint64_t *out_keys);
+int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t *counts,
+                          void *dst_records);
+int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n_alignments);
+
 /* copy between any two of {host, device} on the handle's stream, then wait */
 int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes);
 

@@ -104,9 +104,9 @@ struct ipx_handle {
     uint64_t seen_words = 0, seen_records = 0;     // for the capacity estimate
     uint64_t reserved_records = 0;
     bool digs_stale = false;     // dig_a no longer holds digit 0 of items_a (after a sort)
-    DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2;
+    DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2, d_xchg;
     // pinned host
-    void *pin_small = nullptr;     // 256 bytes of read-back scalars
+    void *pin_small = nullptr;     // 4 KiB of read-back scalars
     void *pin_out = nullptr, *pin_out2 = nullptr;
     size_t pin_out_cap = 0, pin_out2_cap = 0;
     ipx_table table{};
@@ -301,7 +301,7 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
-    if (hipHostMalloc(&h->pin_small, 256, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
+    if (hipHostMalloc(&h->pin_small, 4096, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
     int rc = ensure(h, h->counters, sizeof(Counters));
     if (!rc) rc = ensure(h, h->pass_skip, 16 * sizeof(uint32_t));
     if (!rc) rc = ensure(h, h->rank_skip, 16 * sizeof(uint32_t));
@@ -320,7 +320,7 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->pass_skip, &h->scratch, &h->out_arena,
-                      &h->rank_skip, &h->d_small, &h->out_arena2})
+                      &h->rank_skip, &h->d_small, &h->out_arena2, &h->d_xchg})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -776,7 +776,7 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
 static const char *const kKernelNames[IPXK_COUNT] = {
     "begin", "k_scan", "k_hist", "k_binscan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
     "k_write_heads", "k_motif", "memset", "k_reduce_a", "k_reduce", "k_finish_junctions", "k_bins",
-    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy"};
+    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt"};
 
 int ipx_profile(ipx_handle *h, int enable) {
     if (!h) return IPX_EINVAL;
@@ -825,6 +825,84 @@ int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creato
     (void)hipEventElapsedTime(&h->fin_ms, h->ev[2], h->ev[3]);
     h->table = *out_from_creator;
     if (err_word != IPX_ERRW_NONE) return report_data_error(h, err_word);
+    return IPX_OK;
+}
+
+// ---- multi-GPU record exchange (ipx_exchange.hip) ------------------------------------
+int ipx_records_pending(const ipx_handle *h, uint64_t *n_records) {
+    if (!h || !n_records) return IPX_EINVAL;
+    *n_records = h->n_records;
+    return IPX_OK;
+}
+
+int ipx_records_sample(ipx_handle *h, uint32_t n_samples, uint64_t *out_keys) {
+    if (!h || (n_samples && !out_keys) || n_samples > 4096) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    if (!n_samples) return IPX_OK;
+    int rc = ensure(h, h->d_xchg, (size_t)4096 * 8 + 2 * 64 * 8);
+    if (rc) return rc;
+    HIPCHK(ipx_launch_sample(h->stream, h->items_a.as<uint4>(), h->n_records, h->key, n_samples,
+                             h->d_xchg.as<unsigned long long>()));
+    HIPCHK(hipMemcpyAsync(out_keys, h->d_xchg.p, (size_t)n_samples * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return IPX_OK;
+}
+
+int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t *counts,
+                          void *dst_records) {
+    if (!h || !n_parts || n_parts > 64 || (n_parts > 1 && !splitters) || !counts || (h->n_records && !dst_records))
+        return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    int rc = ensure(h, h->d_xchg, (size_t)4096 * 8 + 2 * 64 * 8);
+    if (rc) return rc;
+    unsigned long long *d_spl = h->d_xchg.as<unsigned long long>() + 4096;
+    unsigned long long *d_cnt = d_spl + 64;
+    unsigned long long host[128];
+    memset(host, 0, sizeof host);
+    for (uint32_t i = 0; i + 1 < n_parts; ++i) host[i] = splitters[i];
+    ProfScope prof_scope(&h->prof);
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    HIPCHK(hipMemcpyAsync(d_spl, host, sizeof host, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(ipx_launch_partition_count(h->stream, h->items_a.as<uint4>(), h->n_records, h->key, n_parts, d_spl, d_cnt));
+    HIPCHK(hipMemcpyAsync(h->pin_small, d_cnt, 64 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    const unsigned long long *c = (const unsigned long long *)h->pin_small;
+    unsigned long long off = 0;
+    for (uint32_t i = 0; i < n_parts; ++i) {
+        counts[i] = c[i];
+        host[64 + i] = off;              // cursors start at the parts' offsets
+        off += c[i];
+    }
+    HIPCHK(hipMemcpyAsync(d_cnt, host + 64, 64 * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(ipx_launch_partition_scatter(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->n_records, h->key,
+                                        n_parts, d_spl, d_cnt, (uint4 *)dst_records));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    return IPX_OK;
+}
+
+int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n_alignments) {
+    if (!h || (n && !records)) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    // the handle's own records are replaced
+    h->n_records = 0;
+    h->digs_stale = false;
+    int rc = reset_counters(h);
+    if (rc) return rc;
+    if ((rc = grow_records(h, n))) return rc;
+    ProfScope prof_scope(&h->prof);
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    HIPCHK(ipx_launch_adopt(h->stream, (const uint4 *)records, n, 0, h->items_a.as<uint4>(), h->pays.as<uint4>(),
+                            h->dig_a.as<uint8_t>(), h->counters.as<Counters>()));
+    HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    const Counters *c = (const Counters *)h->pin_small;
+    for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
+    h->n_records = n;
+    h->n_alignments = n_alignments;
     return IPX_OK;
 }
 

@@ -86,6 +86,28 @@ struct GenomeDev {
 
 static inline uint64_t ipx_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__
+// fields of a packed sort key (see the record layout above)
+struct KeyParts { uint32_t rank, start, end, off16; };
+
+__device__ __forceinline__ KeyParts unpack_key(const uint4 &it, const KeyLayout &kl) {
+    const uint64_t lo = (uint64_t)it.x | ((uint64_t)it.y << 32);
+    const uint64_t hi = it.z;
+    KeyParts k;
+    k.off16 = (uint32_t)lo & 0xffffu;
+    const uint32_t len = (uint32_t)((lo >> 16) & ((kl.len_bits >= 32) ? 0xffffffffull : ((1ull << kl.len_bits) - 1)));
+    const uint32_t s1 = 16 + kl.len_bits, s2 = s1 + 32;
+    uint64_t st = lo >> s1;
+    if (s1 > 32) st |= hi << (64 - s1);
+    k.start = (uint32_t)st;
+    uint64_t rk = (s2 < 64) ? ((lo >> s2) | (hi << (64 - s2))) : (hi >> (s2 - 64));
+    k.rank = (uint32_t)(rk & ((kl.rank_bits >= 32) ? 0xffffffffull : ((1ull << kl.rank_bits) - 1)));
+    k.end = k.start + len;
+    return k;
+}
+
+#endif
+
 // ---- per-kernel event timing (ipx_profile / ipx_profile_read) -----------------
 // Launchers call ipx_prof_mark(stream, id) right after a launch; the interval since
 // the previous mark on the stream is charged to `id`.  A no-op unless profiling is on.
@@ -94,7 +116,7 @@ enum IpxKernelId {
     IPXK_SCAN, IPXK_SORT_HIST, IPXK_SORT_SCAN, IPXK_SORT_SKIP, IPXK_SORT_SCATTER,
     IPXK_COUNT_HEADS, IPXK_SCAN_U32, IPXK_WRITE_HEADS, IPXK_MOTIF, IPXK_MEMSET, IPXK_PHASE_A,
     IPXK_PHASE_B, IPXK_FINISH_J, IPXK_BINS, IPXK_EMIT_BINS, IPXK_EMIT_J, IPXK_EMIT_IJUNC,
-    IPXK_COPY, IPXK_COUNT
+    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_COUNT
 };
 void ipx_prof_mark(hipStream_t s, int id);
 
@@ -113,3 +135,17 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
 // in == out allowed; block_sums needs div_up(n,4096)+1 words; total may be NULL
 hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
                                uint32_t *block_sums, uint32_t *total);
+
+// ipx_exchange.hip: key-range partitioning of the pending records for the multi-GPU exchange
+hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
+                             uint32_t n_samples, unsigned long long *out /* device */);
+hipError_t ipx_launch_partition_count(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
+                                      uint32_t n_parts, const unsigned long long *splitters /* device */,
+                                      unsigned long long *counts /* device, n_parts, zeroed */);
+hipError_t ipx_launch_partition_scatter(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
+                                        const KeyLayout &kl, uint32_t n_parts,
+                                        const unsigned long long *splitters /* device */,
+                                        unsigned long long *cursors /* device, n_parts: start offsets */,
+                                        uint4 *out_records /* 2 uint4 per record */);
+hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
+                            uint4 *pays, uint8_t *digs, Counters *counters);

@@ -1,0 +1,177 @@
+// ipx_exchange.hip -- multi-GPU record exchange (no reference counterpart).
+//
+// Alignments shard over the GPUs by contiguous read ranges, but a junction's records
+// must meet on ONE GPU to be reduced with the reference's order-dependent semantics.
+// Records therefore move once, over xGMI, by key range: every rank splits its pending
+// records at the same splitters (partition key = chromosome rank << 32 | intron start,
+// so all records of a junction land in one part), the parts are exchanged with one
+// all_to_all, and each rank sorts + reduces the key range it owns.  Every record carries
+// its global order64, so nothing depends on the arrival order.
+#include "ipx_common.h"
+
+namespace {
+
+constexpr uint32_t MAX_PARTS = 64;
+
+__device__ __forceinline__ unsigned long long part_key(const uint4 &it, const KeyLayout &kl) {
+    const KeyParts k = unpack_key(it, kl);
+    return ((unsigned long long)k.rank << 32) | k.start;
+}
+
+// number of splitters <= key  (splitters ascending)
+__device__ __forceinline__ uint32_t part_of(unsigned long long key, const unsigned long long *spl, uint32_t n_parts) {
+    uint32_t p = 0;
+    for (uint32_t i = 0; i + 1 < n_parts; ++i) p += (spl[i] <= key) ? 1u : 0u;
+    return p;
+}
+
+__global__ void k_sample(const uint4 *__restrict__ items, uint64_t n, KeyLayout kl, uint32_t n_samples,
+                         unsigned long long *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    const uint64_t idx = n ? (uint64_t)(((unsigned __int128)i * n) / n_samples) : 0;
+    out[i] = n ? part_key(items[idx < n ? idx : n - 1], kl) : ~0ull;
+}
+
+__global__ __launch_bounds__(256) void k_part_count(const uint4 *__restrict__ items, uint64_t n, KeyLayout kl,
+                                                    uint32_t n_parts, const unsigned long long *__restrict__ spl_g,
+                                                    unsigned long long *__restrict__ counts) {
+    __shared__ unsigned long long spl[MAX_PARTS];
+    __shared__ uint32_t c[MAX_PARTS];
+    if (threadIdx.x < MAX_PARTS) {
+        c[threadIdx.x] = 0;
+        spl[threadIdx.x] = (threadIdx.x + 1 < n_parts) ? spl_g[threadIdx.x] : ~0ull;
+    }
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        atomicAdd(&c[part_of(part_key(items[i], kl), spl, n_parts)], 1u);
+    __syncthreads();
+    if (threadIdx.x < n_parts && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c[threadIdx.x]);
+}
+
+// one tile of 2048 records per block iteration: count per part in LDS, reserve each part's
+// range with one atomic, then place the records (item, payload) pair by pair
+__global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ items, const uint4 *__restrict__ pays,
+                                                      uint64_t n, KeyLayout kl, uint32_t n_parts,
+                                                      const unsigned long long *__restrict__ spl_g,
+                                                      unsigned long long *__restrict__ cursors,
+                                                      uint4 *__restrict__ out) {
+    __shared__ unsigned long long spl[MAX_PARTS];
+    __shared__ uint32_t c[MAX_PARTS];
+    __shared__ unsigned long long base[MAX_PARTS];
+    if (threadIdx.x < MAX_PARTS) spl[threadIdx.x] = (threadIdx.x + 1 < n_parts) ? spl_g[threadIdx.x] : ~0ull;
+    const uint64_t n_tiles = (n + 2047) / 2048;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x < MAX_PARTS) c[threadIdx.x] = 0;
+        __syncthreads();
+        uint4 it[8];
+        uint32_t part[8], local[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; ++r) {
+            const uint64_t i = tile * 2048 + r * 256 + threadIdx.x;
+            part[r] = 0xffffffffu;
+            if (i < n) {
+                it[r] = items[i];
+                part[r] = part_of(part_key(it[r], kl), spl, n_parts);
+                local[r] = atomicAdd(&c[part[r]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < n_parts)
+            base[threadIdx.x] = c[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)c[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < 8; ++r) {
+            if (part[r] != 0xffffffffu) {
+                const unsigned long long pos = base[part[r]] + local[r];
+                out[2 * pos] = it[r];
+                out[2 * pos + 1] = pays[it[r].w];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// received records -> the handle's record arrays (record index = position), digit-0 bytes,
+// OR/AND of the keys
+__global__ __launch_bounds__(256) void k_adopt(const uint4 *__restrict__ rec, uint64_t n, uint64_t first_index,
+                                               uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                               uint8_t *__restrict__ digs, Counters *counters) {
+    __shared__ uint32_t kb_s[4][6];
+    uint32_t v[6] = {0u, 0u, 0u, ~0u, ~0u, ~0u};
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        uint4 it = rec[2 * i];
+        const uint64_t idx = first_index + i;
+        it.w = (uint32_t)idx;
+        items[idx] = it;
+        pays[idx] = rec[2 * i + 1];
+        digs[idx] = (uint8_t)it.x;
+        v[0] |= it.x; v[1] |= it.y; v[2] |= it.z;
+        v[3] &= it.x; v[4] &= it.y; v[5] &= it.z;
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(v[k], d);
+            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
+        }
+        if (lane == 0) kb_s[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t t = threadIdx.x;
+        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        if (t < 3) {
+            const uint32_t o = x0 | x1 | x2 | x3;
+            if (o) atomicOr(&counters->key_or[t], o);
+        } else {
+            const uint32_t a = x0 & x1 & x2 & x3;
+            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
+                             uint32_t n_samples, unsigned long long *out) {
+    if (!n_samples) return hipSuccess;
+    hipLaunchKernelGGL(k_sample, dim3((n_samples + 255) / 256), dim3(256), 0, s, items, n, kl, n_samples, out);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_partition_count(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
+                                      uint32_t n_parts, const unsigned long long *splitters,
+                                      unsigned long long *counts) {
+    if (n_parts > MAX_PARTS) return hipErrorInvalidValue;
+    uint64_t blocks = ipx_div_up(n ? n : 1, 2048);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_part_count, dim3((uint32_t)blocks), dim3(256), 0, s, items, n, kl, n_parts, splitters, counts);
+    ipx_prof_mark(s, IPXK_PARTITION);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_partition_scatter(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
+                                        const KeyLayout &kl, uint32_t n_parts, const unsigned long long *splitters,
+                                        unsigned long long *cursors, uint4 *out_records) {
+    if (n_parts > MAX_PARTS) return hipErrorInvalidValue;
+    if (!n) return hipSuccess;
+    uint64_t blocks = ipx_div_up(n, 2048);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_part_scatter, dim3((uint32_t)blocks), dim3(256), 0, s, items, pays, n, kl, n_parts, splitters,
+                       cursors, out_records);
+    ipx_prof_mark(s, IPXK_PARTITION);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
+                            uint4 *pays, uint8_t *digs, Counters *counters) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = ipx_div_up(n, 2048);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adopt, dim3((uint32_t)blocks), dim3(256), 0, s, records, n, first_index, items, pays, digs,
+                       counters);
+    ipx_prof_mark(s, IPXK_ADOPT);
+    return hipGetLastError();
+}

@@ -72,24 +72,6 @@ __global__ __launch_bounds__(256) void k_count_heads(const uint4 *__restrict__ i
     if (lane == 0) { chunk_j[chunk] = cj; chunk_b[chunk] = cb; }
 }
 
-struct KeyParts { uint32_t rank, start, end, off16; };
-
-__device__ __forceinline__ KeyParts unpack_key(const uint4 &it, const KeyLayout &kl) {
-    const uint64_t lo = (uint64_t)it.x | ((uint64_t)it.y << 32);
-    const uint64_t hi = it.z;
-    KeyParts k;
-    k.off16 = (uint32_t)lo & 0xffffu;
-    const uint32_t len = (uint32_t)((lo >> 16) & ((kl.len_bits >= 32) ? 0xffffffffull : ((1ull << kl.len_bits) - 1)));
-    const uint32_t s1 = 16 + kl.len_bits, s2 = s1 + 32;
-    uint64_t st = lo >> s1;
-    if (s1 > 32) st |= hi << (64 - s1);
-    k.start = (uint32_t)st;
-    uint64_t rk = (s2 < 64) ? ((lo >> s2) | (hi << (64 - s2))) : (hi >> (s2 - 64));
-    k.rank = (uint32_t)(rk & ((kl.rank_bits >= 32) ? 0xffffffffull : ((1ull << kl.rank_bits) - 1)));
-    k.end = k.start + len;
-    return k;
-}
-
 // junction / bin descriptors at the segment heads
 __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ items,
                                                      uint64_t n, KeyLayout kl,

@@ -181,6 +181,76 @@ def table_to_torch(ex, t, device):
     return out
 
 
+class RecordExchanger:
+    """Multi-GPU by key range: every rank scans its own alignments, the junction RECORDS are
+    exchanged once (all_to_all over RCCL) so that each rank owns a contiguous key range, and
+    each rank sorts + reduces its range with the ordinary single-GPU finalize.  The table stays
+    distributed (rank order = key order); ijunc is made global with one all_gather of the
+    creation orders.  Cheaper than merging tables whenever the tables are not much smaller
+    than the records (bench workload: 8 M histogram bins per 10 M records)."""
+
+    N_SAMPLES = 512
+
+    def __init__(self, device, group=None, comm_device=None):
+        self.device, self.group = device, group
+        # gloo rehearsal on one GPU: collectives on CPU copies
+        self.comm_device = comm_device if comm_device is not None else device
+
+    def _to_comm(self, t):
+        return t if t.device == self.comm_device else t.to(self.comm_device)
+
+    def run(self, ex, n_alignments_local=0):
+        """-> (ipx_table of this rank's key range, device memory; global ijunc per row as a tensor)."""
+        from . import _lib as L
+        import numpy as np
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        n_local = ex.records_pending()
+        # 1. common splitters from everybody's samples
+        smp = ex.records_sample(self.N_SAMPLES).astype(np.int64)        # ~0 (no records) becomes -1
+        t = torch.from_numpy(smp).to(self.comm_device)
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t, group=self.group)
+        allk = torch.cat(bufs)
+        allk = torch.sort(allk[allk >= 0]).values
+        if allk.numel():
+            q = (torch.arange(1, world, device=allk.device) * allk.numel()) // world
+            splitters = allk[q].cpu().numpy().astype(np.uint64)
+        else:
+            splitters = np.full(world - 1, np.iinfo(np.int64).max, np.uint64)
+        # 2. partition my records by key range
+        send = torch.empty(max(n_local, 1) * 32, dtype=torch.uint8, device=self.device)
+        counts = ex.records_partition(splitters, send.data_ptr())
+        # 3. who sends how much to whom, then the exchange itself
+        c = torch.from_numpy(counts.astype(np.int64)).to(self.comm_device)
+        cm = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(cm, c, group=self.group)
+        recv_counts = [int(x[rank].item()) for x in cm]
+        n_recv = sum(recv_counts)
+        send_c = self._to_comm(send[:n_local * 32])
+        recv_c = torch.empty(max(n_recv, 1) * 32, dtype=torch.uint8, device=self.comm_device)
+        dist.all_to_all_single(recv_c[:n_recv * 32], send_c, output_split_sizes=[x * 32 for x in recv_counts],
+                               input_split_sizes=[int(x) * 32 for x in counts.tolist()], group=self.group)
+        recv = recv_c if recv_c.device == self.device else recv_c.to(self.device)
+        if recv.device.type == "cuda":
+            torch.cuda.synchronize(recv.device)
+        # 4. the key range is now local: ordinary finalize
+        ex.records_adopt(n_recv, recv.data_ptr(), n_alignments_local)
+        rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
+        if rc:
+            ex._check(rc)
+        # 5. sjN numbering is global: rank of the creation order over all ranks' junctions
+        n = int(table.n_junctions)
+        co = torch.empty(n, dtype=torch.int64, device=self.device)
+        if n:
+            ex._check(ex.lib.ipx_copy(ex.h, co.data_ptr(), table.creator_order, n * 8))
+        parts = _all_gather_var(self._to_comm(co), self.group)
+        all_co = torch.sort(torch.cat(parts)).values
+        ijunc = torch.searchsorted(all_co, self._to_comm(co))
+        self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
+        return table, ijunc
+
+
 class TableMerger:
     """bench.py / multi-GPU driver: local shard tables -> merged table over RCCL."""
 

@@ -110,6 +110,30 @@ class JunctionsExtractor:
         self._check(self.lib.ipx_push_batch(self.h, C.byref(b)))
         self.next_read_index = base_read_index + n
 
+    # -- multi-GPU record exchange ------------------------------------------
+    def records_pending(self):
+        n = C.c_uint64(0)
+        self._check(self.lib.ipx_records_pending(self.h, C.byref(n)))
+        return int(n.value)
+
+    def records_sample(self, n_samples):
+        out = np.zeros(n_samples, np.uint64)
+        self._check(self.lib.ipx_records_sample(self.h, n_samples, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def records_partition(self, splitters, dst_ptr):
+        """splitters: ascending uint64 keys (n_parts - 1 of them); dst_ptr: device buffer with room
+        for 32 bytes per pending record.  -> counts per part."""
+        spl = np.ascontiguousarray(splitters, np.uint64)
+        n_parts = len(spl) + 1
+        counts = np.zeros(n_parts, np.uint64)
+        self._check(self.lib.ipx_records_partition(self.h, n_parts, spl.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   counts.ctypes.data_as(C.POINTER(C.c_uint64)), dst_ptr))
+        return counts
+
+    def records_adopt(self, n, src_ptr, n_alignments=0):
+        self._check(self.lib.ipx_records_adopt(self.h, n, src_ptr, n_alignments))
+
     def finalize_raw(self, memory=L.IPX_MEM_HOST):
         t = L.Table()
         rc = self.lib.ipx_finalize(self.h, memory, C.byref(t))

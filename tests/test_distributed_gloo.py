@@ -108,15 +108,7 @@ def _worker(rank, world, port, genome, q):
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("genome", [False, True])
 def test_shard_merge_equals_single_run(world, genome, oracle_lib):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, genome, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    ok, msg, n = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    from tests.mp_util import run_workers
+    ok, msg, n = run_workers(_worker, world, (_free_port(), genome), timeout=300)
     assert ok, "merged table differs from the single run in: %s" % msg
     assert n > 100

@@ -1,5 +1,6 @@
-"""GPU: ipx_finalize_shard on two ranks sharing the one test GPU, tables merged over
-gloo, against a single oracle run (the RCCL path differs only in the backend)."""
+"""GPU: multi-GPU record exchange (key-range all_to_all) on two ranks sharing the one test
+GPU, collectives over gloo; the concatenation of the ranks' tables must equal a single
+oracle run.  The RCCL path differs only in the backend and in skipping the CPU staging."""
 import os
 import socket
 
@@ -25,32 +26,34 @@ def _worker(rank, world, port, genome, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import ctypes as C
         import tempfile
         import intronprospector_amd as ipa
-        from intronprospector_amd import synth, _lib as L
-        from intronprospector_amd.distributed import merge_shard_tables, table_to_torch
+        from intronprospector_amd import synth
+        from intronprospector_amd.distributed import RecordExchanger, table_to_torch, _all_gather_var
         from tests.oracle_binding import Oracle
         params, fasta, gen2 = {}, None, None
         if genome:
-            batch, names, gen = synth.short_reads(40_000, seed=31, n_targets=3, target_len=2_800_000, n_sites=500, genome=True)
+            batch, names, gen = synth.short_reads(60_000, seed=41, n_targets=4, target_len=2_800_000, n_sites=700, genome=True)
             fasta = os.path.join(tempfile.mkdtemp(), "g.fa")
             gen.write_fasta(fasta)
             params = {"junction_filter": 2}
             gen2 = (gen.names, [(t, m, len(s)) for (t, m), s in zip(gen.twobit(), gen.seqs)])
         else:
-            batch, names, _ = synth.short_reads(40_000, seed=32, n_targets=3, target_len=2_800_000, n_sites=500)
+            batch, names, _ = synth.short_reads(60_000, seed=42, n_targets=4, target_len=2_800_000, n_sites=700)
         n = len(batch["tid"])
         cuts = np.linspace(0, n, world + 1).astype(int)
         lo, hi = int(cuts[rank]), int(cuts[rank + 1])
         ex = ipa.JunctionsExtractor(targets=names, genome=gen2, **params)
         ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
-        fc, al = L.Table(), L.Table()
-        rc = ex.lib.ipx_finalize_shard(ex.h, L.IPX_MEM_DEVICE, C.byref(fc), C.byref(al))
-        assert rc == 0
-        t_fc = table_to_torch(ex, fc, "cpu")
-        t_al = table_to_torch(ex, al, "cpu")
-        merged = merge_shard_tables(t_fc, t_al, lo << 20)
+        xch = RecordExchanger(torch.device("cuda", 0), comm_device=torch.device("cpu"))
+        table, ijunc = xch.run(ex, hi - lo)
+        t = table_to_torch(ex, table, "cpu")
+        t["ijunc"] = ijunc.cpu()
+        # gather every rank's rows (rank order = key order)
+        gathered = {k: torch.cat(_all_gather_var(t[k])) for k in
+                    ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc", "counts",
+                     "hist_value", "hist_count")}
+        nper = _all_gather_var(torch.tensor([t["target"].shape[0]]))
         ex.close()
         if rank == 0:
             ora = Oracle(targets=names, genome_fasta=fasta, **params)
@@ -60,25 +63,25 @@ def _worker(rank, world, port, genome, q):
             oo = np.lexsort((ref["intron_end"], ref["intron_start"], ref["target"]))
             bad = []
             for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc"):
-                a, b = merged[k].numpy().astype(np.int64), ref[k][oo].astype(np.int64)
+                a, b = gathered[k].numpy().astype(np.int64), ref[k][oo].astype(np.int64)
                 if a.shape != b.shape or not np.array_equal(a, b):
                     bad.append(k)
-            if not bad and not np.array_equal(merged["counts"].numpy().astype(np.uint64), ref["counts"][oo]):
+            if not bad and not np.array_equal(gathered["counts"].numpy().astype(np.uint64), ref["counts"][oo]):
                 bad.append("counts")
             if not bad:
                 starts = np.concatenate([[0], np.cumsum(ref["n_offsets"].astype(np.int64))])
                 flat = np.concatenate([ref["offsets"][starts[i]:starts[i + 1]] for i in oo])
-                got = np.repeat(merged["hist_value"].numpy(), merged["hist_count"].numpy())
+                got = np.repeat(gathered["hist_value"].numpy(), gathered["hist_count"].numpy())
                 if not np.array_equal(flat.astype(np.int64), got.astype(np.int64)):
                     bad.append("offsets")
-            q.put((bad, len(oo)))
+            q.put((bad, len(oo), [int(x.item()) for x in nper]))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("genome", [False, True])
-def test_two_shards_on_gpu_merge_to_single_run(genome, oracle_lib):
+def test_record_exchange_two_ranks_equals_single_run(genome, oracle_lib):
     from tests.mp_util import run_workers
-    bad, n = run_workers(_worker, 2, (_free_port(), genome), timeout=300)
-    assert not bad, "merged shard tables differ from the single run in: %s" % bad
-    assert n > 100
+    bad, n, nper = run_workers(_worker, 2, (_free_port(), genome), timeout=300)
+    assert not bad, "exchanged tables differ from the single run in: %s" % bad
+    assert n > 100 and min(nper) > 0, nper       # both ranks own part of the key space

@@ -103,6 +103,8 @@ struct ipx_handle {
     uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
     uint64_t seen_words = 0, seen_records = 0;     // for the capacity estimate
     uint64_t reserved_records = 0;
+    bool force_lane_scan = true;   // false with IPX_SCAN=ops in the environment: try ipx_scan_ops.hip first
+    unsigned long long err_word_host = IPX_ERRW_NONE;
     bool digs_stale = false;     // dig_a no longer holds digit 0 of items_a (after a sort)
     DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2, d_xchg;
     // pinned host
@@ -231,6 +233,7 @@ int reset_counters(ipx_handle *h) {
     c.n_records = h->n_records;
     c.err_word = IPX_ERRW_NONE;
     for (int k = 0; k < 3; ++k) { c.key_or[k] = 0; c.key_and[k] = ~0u; h->key_or[k] = 0; h->key_and[k] = ~0u; }
+    h->err_word_host = IPX_ERRW_NONE;
     HIPCHK(hipMemcpyAsync(h->counters.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return IPX_OK;
@@ -271,6 +274,7 @@ void fill_data_error(ipx_handle *h, unsigned long long w) {
             snprintf(e.detail, sizeof e.detail, "%s",
                      detail == 1 ? "more than 2^20-1 junction records in one alignment"
                      : detail == 2 ? "alignment spans 2^32 or more reference bases"
+                     : detail == 3 ? "alignment's CIGAR words lie outside the batch's CIGAR array"
                                    : "alignment tid is not a valid target index");
             break;
     }
@@ -298,6 +302,12 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
     ipx_handle *h = new (std::nothrow) ipx_handle();
     if (!h) return IPX_ENOMEM;
     h->params = *params;
+    {
+        // The per-operation scan (ipx_scan_ops.hip) is correct but, in its round-1 form, slower than
+        // the lane-per-alignment kernel (dependent loads per 64-word chunk): opt in with IPX_SCAN=ops.
+        const char *e = getenv("IPX_SCAN");
+        h->force_lane_scan = !(e && strcmp(e, "ops") == 0);
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
@@ -456,32 +466,44 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     sp.key = h->key;
 
     ProfScope prof_scope(&h->prof);
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // state to return to if a scan has to be repeated
+    Counters before{};
+    before.n_records = h->n_records;
+    before.err_word = h->err_word_host;
+    for (int k = 0; k < 3; ++k) { before.key_or[k] = h->key_or[k]; before.key_and[k] = h->key_and[k]; }
+    bool use_ops = !h->force_lane_scan;
+    for (int attempt = 0; attempt < 4; ++attempt) {
         ipx_prof_mark(h->stream, IPXK_BEGIN);
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
-        HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                               h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
+        if (use_ops)
+            HIPCHK(ipx_launch_scan_ops(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                                       h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
+        else
+            HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                                   h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
-        if (c->n_records <= h->rec_cap) {
+        const bool layout_bad = use_ops && c->pad[0] != 0;
+        if (!layout_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
+            h->err_word_host = c->err_word;
             h->seen_words += nw;
             h->seen_records += c->n_records - h->n_records;
             h->n_records = c->n_records;
             break;
         }
-        // the estimate was too small: records beyond the capacity were counted but not
-        // stored.  Make room for exactly what this batch needs and scan it again.
-        if (attempt == 1) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
+        if (attempt == 3) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
+        // Either the per-operation scan cannot walk this CIGAR layout (words not back to back in
+        // alignment order): repeat with the lane-per-alignment kernel.  Or the capacity estimate was
+        // too small: records beyond it were counted but not stored; make room and scan again.
         const uint64_t need = c->n_records;
-        Counters reset = *c;
-        reset.n_records = h->n_records;
-        HIPCHK(hipMemcpyAsync(h->counters.p, &reset, sizeof reset, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->counters.p, &before, sizeof before, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        if ((rc = grow_records(h, need))) return rc;
+        if (layout_bad) use_ops = false;
+        else if ((rc = grow_records(h, need))) return rc;
     }
     (void)hipEventElapsedTime(&h->push_ms, h->ev[0], h->ev[1]);
     h->n_alignments += n;
@@ -635,7 +657,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             SortPlan rp{};
             for (uint32_t d = 0; d < 7; ++d) rp.digits[rp.n++] = d;      // 54-bit creation order
             HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
-                                   ipx_sort_workspace_bytes(J)));
+                                   ipx_sort_workspace_bytes(J), IPXK_RANK_SORT));
             HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));
         }
         if (err_word != IPX_ERRW_NONE && ((err_word >> 8) & 3u) == IPX_ERRK_GENOME) {
@@ -776,7 +798,7 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
 static const char *const kKernelNames[IPXK_COUNT] = {
     "begin", "k_scan", "k_hist", "k_binscan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
     "k_write_heads", "k_motif", "memset", "k_reduce_a", "k_reduce", "k_finish_junctions", "k_bins",
-    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt"};
+    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt", "ijunc_rank_sort"};
 
 int ipx_profile(ipx_handle *h, int enable) {
     if (!h) return IPX_EINVAL;

@@ -66,7 +66,7 @@ struct Counters {
     unsigned long long n_records;      // allocated so far (may exceed capacity)
     unsigned long long err_word;       // earliest data error, IPX_ERRW_NONE if none
     uint32_t key_or[3], key_and[3];    // OR / AND of all sort keys: bits that never vary need no pass
-    uint32_t pad[2];
+    uint32_t pad[2];                   // [0]: ipx_scan_ops met a CIGAR layout it cannot walk
 };
 
 // digits (8-bit, least significant first) a sort has to process
@@ -116,7 +116,7 @@ enum IpxKernelId {
     IPXK_SCAN, IPXK_SORT_HIST, IPXK_SORT_SCAN, IPXK_SORT_SKIP, IPXK_SORT_SCATTER,
     IPXK_COUNT_HEADS, IPXK_SCAN_U32, IPXK_WRITE_HEADS, IPXK_MOTIF, IPXK_MEMSET, IPXK_PHASE_A,
     IPXK_PHASE_B, IPXK_FINISH_J, IPXK_BINS, IPXK_EMIT_BINS, IPXK_EMIT_J, IPXK_EMIT_IJUNC,
-    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_COUNT
+    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_RANK_SORT, IPXK_COUNT
 };
 void ipx_prof_mark(hipStream_t s, int id);
 
@@ -126,12 +126,19 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
                            uint64_t capacity, Counters *counters);
 
+// ipx_scan_ops.hip: the same scan with one lane per CIGAR operation (needs back-to-back CIGAR
+// words; raises Counters::pad[0] otherwise and the caller re-runs ipx_launch_scan)
+hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_batch &b,
+                               const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
+                               uint64_t capacity, Counters *counters);
+
 // ipx_sort.hip
 size_t ipx_sort_workspace_bytes(uint64_t n);
 // result in buf_b when plan.n is odd, else in buf_a; dig_a/dig_b: digit-byte streams or NULL
+// prof_all: when >= 0, every kernel of this sort is charged to that profiler id
 hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b,
                            bool first_bytes_valid, uint64_t n, const SortPlan &plan, void *workspace,
-                           size_t workspace_bytes);
+                           size_t workspace_bytes, int prof_all = -1);
 // in == out allowed; block_sums needs div_up(n,4096)+1 words; total may be NULL
 hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
                                uint32_t *block_sums, uint32_t *total);

@@ -194,7 +194,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
 // that version spent 5.4 ms on 10 M alignments; the CIGAR words of a tile are re-read
 // from L1/L2.)
 template <uint32_t RPT>
-__global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t base_read_index,
+__global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                               const int32_t *__restrict__ a_tid,
                                               const int32_t *__restrict__ a_pos,
                                               const uint16_t *__restrict__ a_flag,
@@ -233,6 +233,11 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
                 } else {
                     c.pos = a_pos[i];
                     off = a_off[i];
+                    if ((uint64_t)off + nc > n_words) {          // words outside the batch: never dereferenced
+                        const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
+                        err = e < err ? e : err;
+                        nc = 0;
+                    }
                     c.nhc = a_nh[i];
                     c.rank = rank_of_tid[tid];
                     const uint32_t xs = a_xs[i];
@@ -340,11 +345,11 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
     if (blocks > 256ull * 8) blocks = 256ull * 8;
     if (short_reads)
         hipLaunchKernelGGL(k_scan<8>, dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
-                           b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
+                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
     else
         hipLaunchKernelGGL(k_scan<1>, dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
-                           b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
+                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
     ipx_prof_mark(s, IPXK_SCAN);
     return hipGetLastError();

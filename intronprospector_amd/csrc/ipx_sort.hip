@@ -316,7 +316,7 @@ size_t ipx_sort_workspace_bytes(uint64_t n) {
 // histogram reads the items).
 hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b,
                            bool first_bytes_valid, uint64_t n, const SortPlan &plan, void *workspace,
-                           size_t workspace_bytes) {
+                           size_t workspace_bytes, int prof_all) {
     if (n == 0 || plan.n == 0) return hipSuccess;
     if (ipx_sort_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)ipx_div_up(n, SORT_TILE);
@@ -332,16 +332,16 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
             hipLaunchKernelGGL(k_hist<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
         else
             hipLaunchKernelGGL(k_hist<false>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
-        ipx_prof_mark(s, IPXK_SORT_HIST);
+        ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_HIST);
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
-        ipx_prof_mark(s, IPXK_SORT_SCAN);
+        ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);
         if (bytes && next_d != NO_DIGIT)
             hipLaunchKernelGGL(k_scatter<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d, next_d,
                                hist, bin_total, n_tiles);
         else
             hipLaunchKernelGGL(k_scatter<false>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d,
                                next_d, hist, bin_total, n_tiles);
-        ipx_prof_mark(s, IPXK_SORT_SCATTER);
+        ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);
         uint4 *ti = src; src = dst; dst = ti;
         uint8_t *tb = dsrc; dsrc = ddst; ddst = tb;
     }

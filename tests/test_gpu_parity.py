@@ -273,3 +273,54 @@ def test_empty_and_degenerate_inputs():
     t = ex.get_junctions()
     assert t["intron_start"].tolist() == [1010] and t["intron_end"].tolist() == [1110]
     ex.close()
+
+
+def test_per_operation_scan_kernel_matches_oracle(monkeypatch):
+    """ipx_scan_ops.hip (one lane per CIGAR operation, IPX_SCAN=ops) against the oracle on short,
+    long and quirk inputs; it must also fall back cleanly on a CIGAR array that is not laid out
+    back to back."""
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_SCAN", "ops")
+    batch, names, _ = synth.short_reads(60_000, seed=51, n_targets=3, target_len=4_000_000, n_sites=1500)
+    dev, ora, err = _run_both(batch, names, {"min_anchor_length": 3})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+    for max_indel in (0, 3, 36):
+        batch, names, _ = synth.long_reads(800, seed=52, n_targets=2, target_len=9_000_000, n_transcripts=40)
+        dev, ora, err = _run_both(batch, names, {"max_anchor_indel_size": max_indel})
+        assert err is None
+        helpers.compare_tables(dev, ora)
+    p = {"max_anchor_indel_size": 3, "min_intron_length": 10}
+    for cig in ("20M5D9M100N20M", "9M100N20M", "10M50N5M80N10M1D2I30M200N10M", "5S10M100N10M2I10M100N3D10M5H",
+                "10M100N100N10M", "10M100N2D100N10M", "10M100N9D100N10M", "10M100N10M100N10M5P"):
+        dev, ora, _ = _run_both(_one_read(_cig(cig)), ["chr1"], p)
+        helpers.compare_tables(dev, ora)
+    # scattered CIGAR layout: alignments in reverse word order -> lane-per-alignment fallback
+    batch, names, _ = synth.short_reads(3000, seed=53, n_targets=2, target_len=3_000_000, n_sites=100)
+    n = len(batch["tid"])
+    rev_off = np.zeros(n, np.uint32)
+    words = []
+    pos = 0
+    for i in range(n - 1, -1, -1):
+        o, k = int(batch["cigar_off"][i]), int(batch["n_cigar"][i])
+        rev_off[i] = pos
+        words.append(batch["cigar"][o:o + k])
+        pos += k
+    scattered = dict(batch)
+    scattered["cigar_off"] = rev_off
+    scattered["cigar"] = np.concatenate(words)
+    ex = _extractor(targets=names)
+    ex.push(scattered)
+    dev = ex.get_junctions()
+    ora = Oracle(targets=names)
+    ora.process(scattered)
+    helpers.compare_tables(dev, ora.table())
+    ora.close()
+    # offsets that point outside the CIGAR array are reported, never dereferenced
+    broken = dict(batch)
+    broken["cigar_off"] = batch["cigar_off"] + np.uint32(len(batch["cigar"]))
+    ex.clear()
+    ex.push(broken)
+    t = ex.get_junctions()
+    assert t["error"].kind == 5 and "outside the batch" in t["error"].detail
+    ex.close()

@@ -644,18 +644,23 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));
-        HIPCHK(hipMemcpyAsync(small, rb.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(small + 4, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(small, rb.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(small + 8, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->prof.collect();
         ipx_prof_mark(s, IPXK_BEGIN);
         n_valid = small[0];
         n_hist = small[1];
-        err_word = ((const Counters *)(small + 4))->err_word;
+        err_word = ((const Counters *)(small + 8))->err_word;
         // ijunc: rank of the creation order (junctions_extractor.cc:459-460)
         if (n_valid) {
+            // creation-order keys: only the bytes on which they differ (OR ^ AND, small[3..6]) need a pass
             SortPlan rp{};
-            for (uint32_t d = 0; d < 7; ++d) rp.digits[rp.n++] = d;      // 54-bit creation order
+            rp.digits[rp.n++] = 0;
+            for (uint32_t d = 1; d < 8; ++d) {
+                const uint32_t w = d >> 2, sh = (d & 3u) * 8u;
+                if (((small[3 + w] ^ small[5 + w]) >> sh) & 0xffu) rp.digits[rp.n++] = d;
+            }
             HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
                                    ipx_sort_workspace_bytes(J), IPXK_RANK_SORT));
             HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));
@@ -664,7 +669,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             HIPCHK(hipMemsetAsync(detail4, 0, 16, s));
             HIPCHK(ipx_launch_find_genome_error(s, J, rb.first, rb.jmotif, rb.jrank, rb.jstart, rb.jend,
                                                 IPX_ORD_SEQ(err_word), detail4));
-            HIPCHK(hipMemcpyAsync(small + 16, detail4, 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(small + 32, detail4, 16, hipMemcpyDeviceToHost, s));
         }
     } else {
         HIPCHK(hipMemcpyAsync(small + 4, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -746,7 +751,7 @@ static int report_data_error(ipx_handle *h, unsigned long long err_word) {
     uint32_t *small = (uint32_t *)h->pin_small;
     fill_data_error(h, err_word);
     if (h->err.kind == IPX_DATA_GENOME_MISSING || h->err.kind == IPX_DATA_GENOME_SHORT) {
-        const uint32_t *d4 = small + 16;
+        const uint32_t *d4 = small + 32;
         const uint32_t rank = d4[0];
         h->err.target = (rank < h->tid_of_rank.size()) ? h->tid_of_rank[rank] : 0xffffffffu;
         // the acceptor side [end-2,end) is fetched first (g++ evaluates the operands of

@@ -433,35 +433,46 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
     }
 }
 
-// per junction: validity, final strand, genome errors; per-junction bin counting is in k_bins
+// per junction: validity, final strand, genome errors.  Grid-stride with few blocks: the OR of the
+// creators' ordinals leaves each block as ONE atomic (same-address atomics serialise at ~17 ns).
 __global__ __launch_bounds__(256) void k_finish_junctions(uint32_t n_j,
                                                           const unsigned long long *__restrict__ first,
                                                           const unsigned long long *__restrict__ creator,
                                                           const uint32_t *__restrict__ jmotif,
                                                           uint32_t *__restrict__ jvalid,
                                                           uint8_t *__restrict__ jstrand,
-                                                          Counters *counters) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_j) return;
-    const uint32_t m = jmotif[j];
-    if (m & 0x300u) {
-        // the first record of the key is the one whose fetch throws
-        const unsigned long long f = first[j];
-        atomicMin(&counters->err_word,
-                  (f & ~0x3ffull) | (IPX_ERRK_GENOME << 8) | ((m & 0x200u) ? 1u : 0u));
-    }
-    const unsigned long long cr = creator[j];
-    const bool valid = (cr != NONE64) && !(m & 0x300u);
-    jvalid[j] = valid ? 1u : 0u;
-    uint32_t s = '.';
-    if (valid) {
-        s = IPX_ORD_STRAND(cr);
-        if ((m & IPX_MOTIF_PRESENT) && s == '.') {          // correct_strand :431-444
-            if (m & IPX_MOTIF_CANON_P) s = '+';
-            else if (m & IPX_MOTIF_CANON_RC) s = '-';
+                                                          Counters *counters, uint32_t *__restrict__ ord_or) {
+    __shared__ uint32_t or_s[4];
+    uint32_t o = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_j; j += gridDim.x * blockDim.x) {
+        const uint32_t m = jmotif[j];
+        if (m & 0x300u) {
+            // the first record of the key is the one whose fetch throws
+            const unsigned long long f = first[j];
+            atomicMin(&counters->err_word,
+                      (f & ~0x3ffull) | (IPX_ERRK_GENOME << 8) | ((m & 0x200u) ? 1u : 0u));
         }
+        const unsigned long long cr = creator[j];
+        const bool valid = (cr != NONE64) && !(m & 0x300u);
+        jvalid[j] = valid ? 1u : 0u;
+        uint32_t s = '.';
+        if (valid) {
+            o |= (uint32_t)(cr >> IPX_ORD_SHIFT_ORDINAL) & IPX_ORD_MAX_ORDINAL;
+            s = IPX_ORD_STRAND(cr);
+            if ((m & IPX_MOTIF_PRESENT) && s == '.') {          // correct_strand :431-444
+                if (m & IPX_MOTIF_CANON_P) s = '+';
+                else if (m & IPX_MOTIF_CANON_RC) s = '-';
+            }
+        }
+        jstrand[j] = (uint8_t)s;
     }
-    jstrand[j] = (uint8_t)s;
+    for (int d = 32; d >= 1; d >>= 1) o |= __shfl_xor(o, d);
+    if ((threadIdx.x & 63u) == 0) or_s[threadIdx.x >> 6] = o;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t all = or_s[0] | or_s[1] | or_s[2] | or_s[3];
+        if (all) atomicOr(ord_or, all);
+    }
 }
 
 // non-empty bins: flag for compaction
@@ -504,27 +515,51 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jfirstbin,
     const uint32_t *__restrict__ bin_pos,
     const uint32_t *__restrict__ tid_of_rank, const uint32_t *n_valid_total,
-    const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
-    if (j >= n_j || !jvalid[j]) return;
-    const uint32_t o = jpos[j];
-    out.target[o] = tid_of_rank[jrank[j]];
-    out.intron_start[o] = jstart[j];
-    out.intron_end[o] = jend[j];
-    out.anchor_start[o] = amin[j];
-    out.anchor_end[o] = amax[j];
-    out.strand[o] = jstrand[j];
-    out.motif[o] = (uint16_t)(jmotif[j] & 0xf0ffu);
-    out.read_counts[(uint64_t)o * 3 + 0] = counts[(uint64_t)j * 3 + 0];
-    out.read_counts[(uint64_t)o * 3 + 1] = counts[(uint64_t)j * 3 + 1];
-    out.read_counts[(uint64_t)o * 3 + 2] = counts[(uint64_t)j * 3 + 2];
-    const unsigned long long cr = creator[j];
-    out.creator_order[o] = IPX_ORD_SEQ(cr);
-    out.hist_begin[o] = bin_pos[jfirstbin[j]];      // bins are ordered by (junction, offset)
-    // creation order = (read_index, ordinal): sort key for the ijunc ranks
-    const unsigned long long seq = IPX_ORD_SEQ(cr);
-    rank_items[o] = make_uint4((uint32_t)seq, (uint32_t)(seq >> 32), 0u, o);
+    const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items, uint32_t *__restrict__ rank_bits) {
+    __shared__ uint32_t bits_s[4][4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
+    // creation order packed as read_index << (bits of the largest ordinal) | ordinal; the OR / AND of those
+    // keys (rank_bits[1..4]) tell the host which bytes vary, i.e. which radix passes the ranking needs
+    const uint32_t ord_bits = 32u - (uint32_t)__clz((int)rank_bits[0]);
+    uint32_t o0 = 0, o1 = 0, a0 = ~0u, a1 = ~0u;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_j; j += gridDim.x * blockDim.x) {
+        if (!jvalid[j]) continue;
+        const uint32_t o = jpos[j];
+        out.target[o] = tid_of_rank[jrank[j]];
+        out.intron_start[o] = jstart[j];
+        out.intron_end[o] = jend[j];
+        out.anchor_start[o] = amin[j];
+        out.anchor_end[o] = amax[j];
+        out.strand[o] = jstrand[j];
+        out.motif[o] = (uint16_t)(jmotif[j] & 0xf0ffu);
+        out.read_counts[(uint64_t)o * 3 + 0] = counts[(uint64_t)j * 3 + 0];
+        out.read_counts[(uint64_t)o * 3 + 1] = counts[(uint64_t)j * 3 + 1];
+        out.read_counts[(uint64_t)o * 3 + 2] = counts[(uint64_t)j * 3 + 2];
+        const unsigned long long cr = creator[j];
+        out.creator_order[o] = IPX_ORD_SEQ(cr);
+        out.hist_begin[o] = bin_pos[jfirstbin[j]];      // bins are ordered by (junction, offset)
+        const unsigned long long rk = (IPX_ORD_READ(cr) << ord_bits) | ((cr >> IPX_ORD_SHIFT_ORDINAL) & IPX_ORD_MAX_ORDINAL);
+        rank_items[o] = make_uint4((uint32_t)rk, (uint32_t)(rk >> 32), 0u, o);
+        o0 |= (uint32_t)rk; o1 |= (uint32_t)(rk >> 32);
+        a0 &= (uint32_t)rk; a1 &= (uint32_t)(rk >> 32);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        o0 |= __shfl_xor(o0, d); o1 |= __shfl_xor(o1, d);
+        a0 &= __shfl_xor(a0, d); a1 &= __shfl_xor(a1, d);
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) { bits_s[wave][0] = o0; bits_s[wave][1] = o1; bits_s[wave][2] = a0; bits_s[wave][3] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t k = threadIdx.x;
+        if (k < 2) {
+            const uint32_t v = bits_s[0][k] | bits_s[1][k] | bits_s[2][k] | bits_s[3][k];
+            if (v) atomicOr(&rank_bits[1 + k], v);
+        } else {
+            const uint32_t v = bits_s[0][k] & bits_s[1][k] & bits_s[2][k] & bits_s[3][k];
+            if (v != ~0u) atomicAnd(&rank_bits[1 + k], v);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_emit_ijunc(uint32_t n, const uint4 *__restrict__ items,
@@ -582,6 +617,8 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     if ((e = hipMemsetAsync(rb.amax, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.counts, 0, sizeof(uint64_t) * 3 * J, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rb.bin_count, 0, sizeof(uint32_t) * B, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.totals + 2, 0, sizeof(uint32_t) * 3, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rb.totals + 5, 0xff, sizeof(uint32_t) * 2, s)) != hipSuccess) return e;
     ipx_prof_mark(s, IPXK_MEMSET);
     // A record can fail the filter only against a motif and under "canon" (splice_juncs.cc:52-61)
     const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
@@ -597,8 +634,8 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                            rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
         ipx_prof_mark(s, IPXK_PHASE_B);
     }
-    hipLaunchKernelGGL(k_finish_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.first, rb.creator,
-                       rb.jmotif, rb.jvalid, rb.jstrand, counters);
+    hipLaunchKernelGGL(k_finish_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.first, rb.creator,
+                       rb.jmotif, rb.jvalid, rb.jstrand, counters, rb.totals + 2);
     ipx_prof_mark(s, IPXK_FINISH_J);
     hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_flag);
     ipx_prof_mark(s, IPXK_BINS);
@@ -611,9 +648,9 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
                 rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
                 rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
-    hipLaunchKernelGGL(k_emit_junctions, grid1d(J, 256), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
+    hipLaunchKernelGGL(k_emit_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
-                       rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a);
+                       rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a, rb.totals + 2);
     ipx_prof_mark(s, IPXK_EMIT_J);
     return hipGetLastError();
 }

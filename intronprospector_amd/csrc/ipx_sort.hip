@@ -35,50 +35,54 @@ __device__ __forceinline__ uint32_t digit_of(const uint4 &it, uint32_t d) {
     return (w >> ((d & 3u) * 8u)) & 0xffu;
 }
 
-// per-tile digit histogram; BYTES: from the digit-byte stream, else from the items
+// per-tile digit histogram; BYTES: from the digit-byte stream, else from the items.
+// A block walks several tiles (the per-tile work is tiny: launch cost would dominate).
 template <bool BYTES>
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__ items,
                                                        const uint8_t *__restrict__ digs, uint64_t n,
                                                        uint32_t d, uint32_t *__restrict__ hist,
                                                        uint32_t n_tiles) {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
-    if (BYTES) {
-        const uint64_t i0 = base + (uint64_t)threadIdx.x * 8;
-        if (i0 + 8 <= n) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(digs + i0);      // tile bases are 2048-aligned
-            // high digits of (nearly) sorted keys: the thread's 8 bytes, often the whole wave's,
-            // are one value -> one LDS add instead of 8 (512) on a single, contended bin
-            const uint32_t b0 = v.x & 0xffu;
-            const bool uni = (v.x == b0 * 0x01010101u) && (v.y == v.x);
-            const uint64_t act = __ballot(1);
-            const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
-            if (__ballot(uni && b0 == first) == act) {
-                if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
-                    atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
-            } else if (uni) {
-                atomicAdd(&h[b0], 8u);
-            } else {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)tile * SORT_TILE;
+        if (BYTES) {
+            const uint64_t i0 = base + (uint64_t)threadIdx.x * 8;
+            if (i0 + 8 <= n) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(digs + i0);      // tile bases are 2048-aligned
+                // high digits of (nearly) sorted keys: the thread's 8 bytes, often the whole wave's,
+                // are one value -> one LDS add instead of 8 (512) on a single, contended bin
+                const uint32_t b0 = v.x & 0xffu;
+                const bool uni = (v.x == b0 * 0x01010101u) && (v.y == v.x);
+                const uint64_t act = __ballot(1);
+                const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
+                if (__ballot(uni && b0 == first) == act) {
+                    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
+                        atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
+                } else if (uni) {
+                    atomicAdd(&h[b0], 8u);
+                } else {
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    atomicAdd(&h[(v.x >> (8 * k)) & 0xffu], 1u);
-                    atomicAdd(&h[(v.y >> (8 * k)) & 0xffu], 1u);
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        atomicAdd(&h[(v.x >> (8 * k)) & 0xffu], 1u);
+                        atomicAdd(&h[(v.y >> (8 * k)) & 0xffu], 1u);
+                    }
                 }
+            } else {
+                for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
             }
         } else {
-            for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
-        }
-    } else {
 #pragma unroll
-        for (uint32_t r = 0; r < SORT_IPT; ++r) {
-            const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[digit_of(items[i], d)], 1u);
+            for (uint32_t r = 0; r < SORT_IPT; ++r) {
+                const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
+                if (i < n) atomicAdd(&h[digit_of(items[i], d)], 1u);
+            }
         }
+        __syncthreads();
+        hist[(uint64_t)threadIdx.x * n_tiles + tile] = h[threadIdx.x];
+        __syncthreads();
     }
-    __syncthreads();
-    hist[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
 }
 
 // block b: hist[b][0..n_tiles) -> exclusive prefix in place, bin_total[b] = sum
@@ -323,15 +327,16 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     uint32_t *hist = (uint32_t *)workspace;
     uint32_t *bin_total = hist + (uint64_t)256 * n_tiles;
     const bool bytes = dig_a != nullptr && dig_b != nullptr;
+    const uint32_t hist_grid = n_tiles < 1024 ? n_tiles : 1024;
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
     for (uint32_t k = 0; k < plan.n; ++k) {
         const uint32_t d = plan.digits[k];
         const uint32_t next_d = (k + 1 < plan.n) ? plan.digits[k + 1] : NO_DIGIT;
         if (bytes && (k > 0 || first_bytes_valid))
-            hipLaunchKernelGGL(k_hist<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
+            hipLaunchKernelGGL(k_hist<true>, dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
         else
-            hipLaunchKernelGGL(k_hist<false>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
+            hipLaunchKernelGGL(k_hist<false>, dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_HIST);
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);

@@ -97,13 +97,20 @@ __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx 
 // The reference's ReadJunctionExtractor::parse_read over one CIGAR.  EMIT=false counts
 // the records that pass junction_qc (and reports a CIGAR error); EMIT=true stores them
 // at slot0, slot0+1, ...  Returns the number of QC-passed records.
-template <bool EMIT>
+struct Pool {                    // LDS staging of a tile's records (k_scan_pool)
+    uint4 *item, *pay;
+    uint32_t *n;
+    uint32_t cap;
+};
+
+// MODE 0: count; MODE 1: store at slot0 + ordinal in the global record arrays; MODE 2: append to the LDS pool
+template <int MODE>
 __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx &c,
                                              const uint32_t *__restrict__ cig, uint32_t nc,
                                              uint64_t slot0, uint64_t capacity,
                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
                                              uint8_t *__restrict__ digs, KeyBits &kb,
-                                             unsigned long long &err) {
+                                             unsigned long long &err, const Pool *pool = nullptr) {
     uint32_t state = ST_LIMBO;
     int64_t target_pos = c.pos, anchor_start = -1, intron_start = -1, intron_end = -1, anchor_end = -1;
     uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
@@ -111,9 +118,16 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
     auto emit = [&]() {
         const Rec r{anchor_start, intron_start, intron_end, anchor_end, lmm, rmm, lind, rind};
         if (qc_pass(p, c, r)) {
-            if (EMIT) {
+            if (MODE == 1) {
                 const uint64_t idx = slot0 + ordinal;
                 if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
+            } else if (MODE == 2) {
+                const uint32_t slot = atomicAdd(pool->n, 1u);
+                if (slot < pool->cap && ordinal <= IPX_ORD_MAX_ORDINAL) {
+                    uint8_t dummy_dig;
+                    KeyBits dummy_kb;
+                    store_record(p, c, r, ordinal, 0, pool->item + slot, pool->pay + slot, &dummy_dig, dummy_kb);
+                }
             }
             ++ordinal;
         }
@@ -193,7 +207,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
 // (One returning atomic per wave and step on a single counter serialises at ~17 ns each:
 // that version spent 5.4 ms on 10 M alignments; the CIGAR words of a tile are re-read
 // from L1/L2.)
-template <uint32_t RPT>
+template <uint32_t RPT, uint32_t POOL>
 __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                               const int32_t *__restrict__ a_tid,
                                               const int32_t *__restrict__ a_pos,
@@ -212,6 +226,12 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
     KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
     __shared__ uint32_t cnt_s[RPT][256], base_s[RPT][256];
     __shared__ unsigned long long tile_slot;
+    // POOL > 0: a tile's records are first staged in LDS by ONE run of the state machines and then
+    // copied out as a block (no second run); a tile that emits more than POOL records falls back to
+    // the count / reserve / re-run scheme below
+    __shared__ uint4 pool_item[POOL ? POOL : 1], pool_pay[POOL ? POOL : 1];
+    __shared__ uint32_t pool_n;
+    const Pool pool{pool_item, pool_pay, &pool_n, POOL};
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + 256ull * RPT - 1) / (256ull * RPT);
 
@@ -252,6 +272,45 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         unsigned long long my_err = IPX_ERRW_NONE;
+        if (POOL) {
+            if (t == 0) pool_n = 0;
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t r = 0; r < RPT; ++r) {
+                const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+                ReadCtx c;
+                uint32_t nc, off;
+                load_ctx(i, c, nc, off, my_err);
+                if (nc) (void)run_read<2>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err, &pool);
+            }
+            __syncthreads();
+            const uint32_t total = pool_n;
+            if (total <= POOL) {
+                if (t == 0) tile_slot = total ? atomicAdd(&counters->n_records, (unsigned long long)total) : 0ull;
+                __syncthreads();
+                const uint64_t slot = tile_slot;
+                for (uint32_t k = t; k < total; k += 256) {
+                    const uint64_t idx = slot + k;
+                    if (idx < capacity) {
+                        uint4 it = pool_item[k];
+                        it.w = (uint32_t)idx;
+                        items[idx] = it;
+                        pays[idx] = pool_pay[k];
+                        digs[idx] = (uint8_t)it.x;
+                        kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                        kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+                    }
+                }
+                unsigned long long e = my_err;
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const unsigned long long o = __shfl_xor(e, d);
+                    e = o < e ? o : e;
+                }
+                if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+                __syncthreads();
+                continue;
+            }
+        }
         // pass 1: count.  Loops over r stay rolled (one copy of the state machine in the
         // code, low register pressure); per-round counts live in LDS.
 #pragma unroll 1
@@ -260,7 +319,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
             ReadCtx c;
             uint32_t nc, off;
             load_ctx(i, c, nc, off, my_err);
-            const uint32_t cn = nc ? run_read<false>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err) : 0;
+            const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err) : 0;
             cnt_s[r][t] = cn;
             // inclusive scan inside the wave
             uint32_t v = cn;
@@ -296,7 +355,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
                     ReadCtx c;
                     uint32_t nc, off;
                     load_ctx(i, c, nc, off, dummy);
-                    (void)run_read<true>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy);
+                    (void)run_read<1>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy);
                 }
             }
         }
@@ -338,17 +397,17 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
                            uint64_t capacity, Counters *counters) {
     if (b.n_alignments == 0) return hipSuccess;
-    // short CIGARs: 8 alignments per thread and tile (2048 per atomic); long ones: 1
+    // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
     const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;
-    const uint64_t per_tile = short_reads ? 2048 : 256;
+    const uint64_t per_tile = short_reads ? 512 : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
-    if (blocks > 256ull * 8) blocks = 256ull * 8;
+    if (blocks > 256ull * 16) blocks = 256ull * 16;
     if (short_reads)
-        hipLaunchKernelGGL(k_scan<8>, dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+        hipLaunchKernelGGL((k_scan<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
     else
-        hipLaunchKernelGGL(k_scan<1>, dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+        hipLaunchKernelGGL((k_scan<1, 0>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
     ipx_prof_mark(s, IPXK_SCAN);

@@ -119,16 +119,21 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
     c.live = 0;
     c.off = (uint32_t)o_begin; c.nc = 0;
     uint64_t next_rid = ra;   // next alignment whose head has not been placed yet
+    uint64_t next_off = o_begin;                         // its offset (uniform), ~0 when there is none
     uint32_t emitted = 0;     // QC-passed records of this span so far
+    uint32_t w_next = (o_begin + lane < o_end) ? a.cigar[o_begin + lane] : 0u;
 
     for (uint64_t c0 = o_begin; c0 < o_end; c0 += 64) {
         const uint64_t o = c0 + lane;
         const bool valid = o < o_end;
-        const uint32_t w = valid ? a.cigar[o] : 0u;
+        const uint32_t w = w_next;
+        // the next chunk's words are requested now and waited for a whole chunk later
+        w_next = (o + 64 < o_end) ? a.cigar[o + 64] : 0u;
         // ---- which alignment does each word belong to: heads of the chunk -------------------
-        head_s[lane] = 0;
+        const bool heads_here = next_off < c0 + 64;                      // uniform: a head may fall in this chunk
+        if (heads_here) head_s[lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        while (next_rid < rb && (uint64_t)a.off[next_rid] < c0 + 64) {   // uniform test: a head may fall in this chunk
+        while (next_rid < rb && next_off < c0 + 64) {
             // 64 candidate alignments at a time; the ones that start inside [c0, c0+64) form a prefix
             const uint64_t r = next_rid + lane;
             bool consumed = false;
@@ -148,10 +153,11 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
             const uint64_t not_consumed = ~__ballot(consumed);
             const uint32_t n_in = not_consumed ? (uint32_t)(__ffsll((unsigned long long)not_consumed) - 1) : 64u;
             next_rid += n_in;
+            next_off = next_rid < rb ? (uint64_t)a.off[next_rid] : ~0ull;
             if (n_in < 64) break;
         }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t hv = head_s[lane];
+        const uint32_t hv = heads_here ? head_s[lane] : 0u;
         const bool is_head = valid && hv != 0;
         const uint64_t mH = __ballot(is_head);
         const int h_k = top_bit(mH & le_mask(lane));                      // my alignment's head lane, -1: carried

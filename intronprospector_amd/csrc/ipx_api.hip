@@ -559,13 +559,11 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         const uint64_t sums1 = ipx_div_up(chunks, 4096) + 2;
         const size_t ws_bytes = std::max(ipx_sort_workspace_bytes(R),
                                          (size_t)((2 * chunks_al + sums1) * sizeof(uint32_t) + 1024));
-        // digits on which the keys differ (OR ^ AND); digit 0 always runs: its bytes come with the records
-        SortPlan plan{};
-        plan.digits[plan.n++] = 0;
-        for (uint32_t d = 1; d < h->key.n_digits; ++d) {
-            const uint32_t w = d >> 2, sh = (d & 3u) * 8u;
-            if (((h->key_or[w] ^ h->key_and[w]) >> sh) & 0xffu) plan.digits[plan.n++] = d;
-        }
+        // one pass per (up to) 8 bits on which the keys differ (OR ^ AND); bits 0..7 always run first:
+        // their digit bytes come with the records
+        const uint32_t vary[3] = {h->key_or[0] ^ h->key_and[0], h->key_or[1] ^ h->key_and[1],
+                                  h->key_or[2] ^ h->key_and[2]};
+        const SortPlan plan = ipx_plan_sort(vary, h->key.total_bits, true);
         if (resort) {
             if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
             if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
@@ -654,13 +652,9 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         err_word = ((const Counters *)(small + 8))->err_word;
         // ijunc: rank of the creation order (junctions_extractor.cc:459-460)
         if (n_valid) {
-            // creation-order keys: only the bytes on which they differ (OR ^ AND, small[3..6]) need a pass
-            SortPlan rp{};
-            rp.digits[rp.n++] = 0;
-            for (uint32_t d = 1; d < 8; ++d) {
-                const uint32_t w = d >> 2, sh = (d & 3u) * 8u;
-                if (((small[3 + w] ^ small[5 + w]) >> sh) & 0xffu) rp.digits[rp.n++] = d;
-            }
+            // creation-order keys: only the bits on which they differ (OR ^ AND, small[3..6]) need passes
+            const uint32_t rvary[3] = {small[3] ^ small[5], small[4] ^ small[6], 0u};
+            const SortPlan rp = ipx_plan_sort(rvary, 64, false);
             HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
                                    ipx_sort_workspace_bytes(J), IPXK_RANK_SORT));
             HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));

@@ -69,11 +69,46 @@ struct Counters {
     uint32_t pad[2];                   // [0]: ipx_scan_ops met a CIGAR layout it cannot walk
 };
 
-// digits (8-bit, least significant first) a sort has to process
+// One radix pass looks at up to 8 key bits taken from at most two runs of bits:
+// digit = bits [lo1, lo1+w1) | bits [lo2, lo2+w2) << w1   (w1 + w2 <= 8, lo2 >= lo1 + w1).
+struct DigitSpec {
+    uint32_t lo1, w1, lo2, w2;
+};
+// passes of a sort, least significant first
 struct SortPlan {
-    uint32_t digits[12];
+    DigitSpec digits[16];
     uint32_t n;
 };
+// Passes that cover exactly the bits set in vary[0..2] (bits on which the keys differ), at most
+// max_bits of them.  first_byte: the first pass is bits 0..7 whatever varies there (its digit bytes
+// were written together with the records).
+static inline SortPlan ipx_plan_sort(const uint32_t vary[3], uint32_t max_bits, bool first_byte) {
+    SortPlan plan{};
+    uint32_t bit = 0;
+    if (first_byte) {
+        plan.digits[plan.n++] = DigitSpec{0, 8, 0, 0};
+        bit = 8;
+    }
+    auto varies = [&](uint32_t b) { return b < max_bits && ((vary[b >> 5] >> (b & 31u)) & 1u); };
+    while (bit < max_bits && plan.n < 16) {
+        while (bit < max_bits && !varies(bit)) ++bit;
+        if (bit >= max_bits) break;
+        DigitSpec d{bit, 0, 0, 0};
+        while (d.w1 < 8 && varies(bit)) { ++d.w1; ++bit; }
+        if (d.w1 < 8) {                                  // room left: take the start of the next run too
+            uint32_t nb = bit;
+            while (nb < max_bits && !varies(nb)) ++nb;
+            if (nb < max_bits) {
+                d.lo2 = nb;
+                while (d.w1 + d.w2 < 8 && varies(nb)) { ++d.w2; ++nb; }
+                bit = nb;
+            }
+        }
+        plan.digits[plan.n++] = d;
+    }
+    if (plan.n == 0) plan.digits[plan.n++] = DigitSpec{0, 8, 0, 0};
+    return plan;
+}
 
 struct GenomeDev {
     const uint32_t *twobit;      // 16 bases per word, all sequences concatenated (word aligned per sequence)

@@ -28,11 +28,19 @@ constexpr uint32_t SORT_THREADS = 256;
 constexpr uint32_t SORT_IPT = 8;                        // items per thread
 constexpr uint32_t SORT_TILE = SORT_THREADS * SORT_IPT; // 2048 items = 32 KiB
 constexpr uint32_t SCAN_TILE = 4096;
-constexpr uint32_t NO_DIGIT = 0xffffffffu;
 
-__device__ __forceinline__ uint32_t digit_of(const uint4 &it, uint32_t d) {
-    const uint32_t w = (d >> 2) == 0 ? it.x : ((d >> 2) == 1 ? it.y : it.z);
-    return (w >> ((d & 3u) * 8u)) & 0xffu;
+// bits [lo, lo+w) of the 96-bit key (w <= 8)
+__device__ __forceinline__ uint32_t key_bits(const uint4 &it, uint32_t lo, uint32_t w) {
+    const uint32_t word = lo >> 5, sh = lo & 31u;
+    const uint32_t w0 = word == 0 ? it.x : (word == 1 ? it.y : it.z);
+    const uint32_t w1 = word == 0 ? it.y : (word == 1 ? it.z : 0u);
+    const uint64_t both = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    return (uint32_t)(both >> sh) & ((1u << w) - 1u);
+}
+__device__ __forceinline__ uint32_t digit_of(const uint4 &it, const DigitSpec &d) {
+    uint32_t v = key_bits(it, d.lo1, d.w1);
+    if (d.w2) v |= key_bits(it, d.lo2, d.w2) << d.w1;
+    return v;
 }
 
 // per-tile digit histogram; BYTES: from the digit-byte stream, else from the items.
@@ -40,7 +48,7 @@ __device__ __forceinline__ uint32_t digit_of(const uint4 &it, uint32_t d) {
 template <bool BYTES>
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__ items,
                                                        const uint8_t *__restrict__ digs, uint64_t n,
-                                                       uint32_t d, uint32_t *__restrict__ hist,
+                                                       DigitSpec d, uint32_t *__restrict__ hist,
                                                        uint32_t n_tiles) {
     __shared__ uint32_t h[256];
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, ui
 
 template <bool WRITE_NEXT>
 __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
-                                                          uint8_t *__restrict__ dig_dst, uint64_t n, uint32_t d,
-                                                          uint32_t next_d, const uint32_t *__restrict__ scanned,
+                                                          uint8_t *__restrict__ dig_dst, uint64_t n, DigitSpec d,
+                                                          DigitSpec next_d, const uint32_t *__restrict__ scanned,
                                                           const uint32_t *__restrict__ bin_total,
                                                           uint32_t n_tiles) {
     __shared__ uint4 tile[SORT_TILE];          // 32 KiB
@@ -331,8 +339,9 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
     for (uint32_t k = 0; k < plan.n; ++k) {
-        const uint32_t d = plan.digits[k];
-        const uint32_t next_d = (k + 1 < plan.n) ? plan.digits[k + 1] : NO_DIGIT;
+        const DigitSpec d = plan.digits[k];
+        const bool has_next = k + 1 < plan.n;
+        const DigitSpec next_d = has_next ? plan.digits[k + 1] : DigitSpec{0, 8, 0, 0};
         if (bytes && (k > 0 || first_bytes_valid))
             hipLaunchKernelGGL(k_hist<true>, dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
         else
@@ -340,7 +349,7 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_HIST);
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);
-        if (bytes && next_d != NO_DIGIT)
+        if (bytes && has_next)
             hipLaunchKernelGGL(k_scatter<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d, next_d,
                                hist, bin_total, n_tiles);
         else

@@ -312,7 +312,7 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
     if (hipHostMalloc(&h->pin_small, 4096, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
-    int rc = ensure(h, h->counters, sizeof(Counters));
+    int rc = ensure(h, h->counters, 256);      // Counters + ipx_scan.hip's copy of the CIGAR tail at byte 128
     if (!rc) rc = ensure(h, h->pass_skip, 16 * sizeof(uint32_t));
     if (!rc) rc = ensure(h, h->rank_skip, 16 * sizeof(uint32_t));
     if (!rc) rc = ensure(h, h->d_small, 64 * sizeof(uint32_t));

@@ -12,6 +12,8 @@
 // Mapping: one lane per alignment; see k_scan below for the tile structure.
 #include "ipx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 enum : uint32_t { ST_LIMBO = 1, ST_LEFT = 2, ST_INTRON = 4, ST_RIGHT = 8 };
@@ -67,9 +69,9 @@ __device__ __forceinline__ bool qc_pass(const ScanParams &p, const ReadCtx &c, c
 
 struct KeyBits { uint32_t o0, o1, o2, a0, a1, a2; };
 
-__device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx &c, const Rec &r,
-                                             uint32_t ordinal, uint64_t idx, uint4 *__restrict__ items,
-                                             uint4 *__restrict__ pays, uint8_t *__restrict__ digs, KeyBits &kb) {
+// key (item.x/y/z; item.w is left 0) and payload words of one record
+__device__ __forceinline__ void pack_record(const ScanParams &p, const ReadCtx &c, const Rec &r,
+                                            uint32_t ordinal, uint4 &item, uint4 &pay) {
     const uint32_t start = (uint32_t)r.intron_start;
     const uint32_t len = (uint32_t)(r.intron_end - r.intron_start);
     const uint32_t off16 = (uint32_t)(r.intron_start - c.pos) & 0xffffu;
@@ -86,12 +88,45 @@ __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx 
     const unsigned long long order = (c.read_index << IPX_ORD_SHIFT_READ) |
                                      ((unsigned long long)ordinal << IPX_ORD_SHIFT_ORDINAL) |
                                      (c.strand << 2) | c.cat;
-    items[idx] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)idx);
-    pays[idx] = make_uint4((uint32_t)order, (uint32_t)(order >> 32), (uint32_t)r.anchor_start,
-                           (uint32_t)r.anchor_end);
-    digs[idx] = (uint8_t)lo;                       // digit 0 for the first sort pass
-    kb.o0 |= (uint32_t)lo; kb.o1 |= (uint32_t)(lo >> 32); kb.o2 |= (uint32_t)hi;
-    kb.a0 &= (uint32_t)lo; kb.a1 &= (uint32_t)(lo >> 32); kb.a2 &= (uint32_t)hi;
+    item = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, 0u);
+    pay = make_uint4((uint32_t)order, (uint32_t)(order >> 32), (uint32_t)r.anchor_start, (uint32_t)r.anchor_end);
+}
+
+// the same from 32-bit offsets relative to the alignment's position pos32 (k_scan_long)
+__device__ __forceinline__ void pack_record_rel(const ScanParams &p, const ReadCtx &c, const Rec &r, uint32_t pos32,
+                                                uint32_t ordinal, uint4 &item, uint4 &pay) {
+    const uint32_t start = pos32 + (uint32_t)r.intron_start;
+    const uint32_t len = (uint32_t)r.intron_end - (uint32_t)r.intron_start;
+    const uint32_t off16 = (uint32_t)r.intron_start & 0xffffu;
+    const uint32_t s1 = 16 + p.key.len_bits;
+    const uint32_t s2 = s1 + 32;
+    uint64_t lo = (uint64_t)off16 | ((uint64_t)len << 16) | ((uint64_t)start << s1);
+    uint64_t hi = (s1 > 32) ? ((uint64_t)start >> (64 - s1)) : 0;
+    if (s2 < 64) {
+        lo |= (uint64_t)c.rank << s2;
+        if (s2 > 32) hi |= (uint64_t)c.rank >> (64 - s2);
+    } else {
+        hi |= (uint64_t)c.rank << (s2 - 64);
+    }
+    const unsigned long long order = (c.read_index << IPX_ORD_SHIFT_READ) |
+                                     ((unsigned long long)ordinal << IPX_ORD_SHIFT_ORDINAL) |
+                                     (c.strand << 2) | c.cat;
+    item = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, 0u);
+    pay = make_uint4((uint32_t)order, (uint32_t)(order >> 32), pos32 + (uint32_t)r.anchor_start,
+                     pos32 + (uint32_t)r.anchor_end);
+}
+
+__device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx &c, const Rec &r,
+                                             uint32_t ordinal, uint64_t idx, uint4 *__restrict__ items,
+                                             uint4 *__restrict__ pays, uint8_t *__restrict__ digs, KeyBits &kb) {
+    uint4 it, pay;
+    pack_record(p, c, r, ordinal, it, pay);
+    it.w = (uint32_t)idx;
+    items[idx] = it;
+    pays[idx] = pay;
+    digs[idx] = (uint8_t)it.x;                     // digit 0 for the first sort pass
+    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
 }
 
 // The reference's ReadJunctionExtractor::parse_read over one CIGAR.  EMIT=false counts
@@ -103,14 +138,16 @@ struct Pool {                    // LDS staging of a tile's records (k_scan_pool
     uint32_t cap;
 };
 
-// MODE 0: count; MODE 1: store at slot0 + ordinal in the global record arrays; MODE 2: append to the LDS pool
+// MODE 0: count; MODE 1: store at slot0 + ordinal in the global record arrays; MODE 2: append to the LDS pool;
+// MODE 3: records with ordinal >= slot0 each reserve their own slot of the global arrays (k_scan_long's rare re-run)
 template <int MODE>
 __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx &c,
                                              const uint32_t *__restrict__ cig, uint32_t nc,
                                              uint64_t slot0, uint64_t capacity,
                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
                                              uint8_t *__restrict__ digs, KeyBits &kb,
-                                             unsigned long long &err, const Pool *pool = nullptr) {
+                                             unsigned long long &err, const Pool *pool = nullptr,
+                                             unsigned long long *n_records = nullptr) {
     uint32_t state = ST_LIMBO;
     int64_t target_pos = c.pos, anchor_start = -1, intron_start = -1, intron_end = -1, anchor_end = -1;
     uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
@@ -121,6 +158,11 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
             if (MODE == 1) {
                 const uint64_t idx = slot0 + ordinal;
                 if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
+            } else if (MODE == 3) {
+                if (ordinal >= slot0 && ordinal <= IPX_ORD_MAX_ORDINAL) {
+                    const uint64_t idx = atomicAdd(n_records, 1ull);
+                    if (idx < capacity) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
+                }
             } else if (MODE == 2) {
                 const uint32_t slot = atomicAdd(pool->n, 1u);
                 if (slot < pool->cap && ordinal <= IPX_ORD_MAX_ORDINAL) {
@@ -391,6 +433,365 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
     }
 }
 
+// ---- long CIGARs ---------------------------------------------------------------------------------
+// k_scan_long is bound by the number of instructions per CIGAR op (a wave64 vector instruction takes
+// four cycles on a SIMD) and by the latency of each lane's private stream of CIGAR words, so:
+//   * every wave owns a contiguous range of alignments and works through it on its own (no block
+//     barriers); a lane that finishes its alignment takes the next one at the top of the loop, so lanes
+//     stay busy although CIGAR lengths differ.  The attributes of the next 64 alignments are staged in
+//     LDS by one round of coalesced loads, so handing a lane its next alignment costs no memory round
+//     trip;
+//   * CIGAR words arrive as 16-byte loads (4 ops) into a ring of LONG_RING register quads; the loop body
+//     is unrolled over the ring, every slot is refilled right after its four ops -- LONG_RING-1 chunks
+//     ahead of use, unconditionally (lanes that need no more words re-read their first chunk), and the
+//     ring is written by nothing else: a lane that was handed an alignment sits out one turn of the
+//     ring ("warm") while the refills bring its first chunks.  So no load result passes through a select
+//     or a copy, which would make the compiler wait for the load where it is issued.  (A 4-byte load per
+//     op re-fetches the lane's 128-byte line from L2 for every op: the lines of all resident lanes do
+//     not fit the 32 KB L1.)  A chunk that would reach past the end of the CIGAR array is read from a
+//     16-word copy of the array's tail instead;
+//   * positions are 32-bit offsets from the alignment's start.  The first op that would carry out of
+//     32 bits parks the alignment: its earlier records stay (they are exact), the rest comes from the
+//     64-bit run_read<3> (never seen on real data; tests/test_gpu_parity.py builds such CIGARs);
+//   * the op is applied with selects, not branches; an op that ends a junction only snapshots six
+//     registers.  junction_qc, key packing and the store run for many lanes at once when enough
+//     snapshots wait (or one is about to be overwritten): a ballot hands out slots of the wave's LDS
+//     pool, and a full pool goes to the record arrays with ONE global atomicAdd.
+// Records of one alignment are told apart by their ordinal, so their place in the arrays is free.
+constexpr uint32_t LONG_POOL = 256;          // records per wave pool (8 KB)
+constexpr uint32_t LONG_DRAIN = 20;          // waiting snapshots that trigger a drain
+constexpr uint32_t LONG_RING = 3;            // 16-byte chunks in flight per lane
+
+struct LongStage {                            // next 64 alignments of a wave, one column per lane
+    uint32_t pos[64], nc[64], meta[64], rank[64], off[64];
+};
+
+struct __attribute__((packed, aligned(4))) Words4 { uint32_t x, y, z, w; };
+
+// copy of the last 8 CIGAR words followed by 8 zero words (see ipx_launch_scan)
+__global__ void k_cigar_tail(const uint32_t *__restrict__ cigar, uint64_t n_words, uint32_t *__restrict__ tail) {
+    const uint32_t t = threadIdx.x;
+    if (t < 16) tail[t] = (t < 8 && n_words >= 8) ? cigar[n_words - 8 + t] : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
+                                                   uint32_t reads_per_wave,
+                                                   const int32_t *__restrict__ a_tid,
+                                                   const int32_t *__restrict__ a_pos,
+                                                   const uint16_t *__restrict__ a_flag,
+                                                   const uint8_t *__restrict__ a_xs,
+                                                   const uint8_t *__restrict__ a_nh,
+                                                   const uint32_t *__restrict__ a_off,
+                                                   const uint32_t *__restrict__ a_nc,
+                                                   const uint32_t *__restrict__ cigar,
+                                                   const uint32_t *__restrict__ tail,
+                                                   const uint32_t *__restrict__ rank_of_tid,
+                                                   uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                                   uint8_t *__restrict__ digs,
+                                                   uint64_t capacity, Counters *counters) {
+    __shared__ uint4 pool_item[4][LONG_POOL], pool_pay[4][LONG_POOL];
+    __shared__ LongStage stage_s[4];
+    __shared__ uint32_t kb_s[4][6];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint4 *const my_item = pool_item[wave], *const my_pay = pool_pay[wave];
+    LongStage &stage = stage_s[wave];
+    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
+    unsigned long long my_err = IPX_ERRW_NONE;
+
+    // four words starting at word w of the CIGAR array (w < n_words); only the address is selected
+    auto load4 = [&](uint64_t w) {
+        const uint32_t *ptr = (w + 4 <= n_words) ? cigar + w : tail + (w - (n_words - 8));
+        const Words4 v = *reinterpret_cast<const Words4 *>(ptr);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
+    uint64_t next = gw * reads_per_wave;          // wave-uniform from here on
+    uint64_t range_end = next + reads_per_wave;
+    if (range_end > n) range_end = n;
+    if (next > n) next = n;
+    uint32_t staged = 0, staged_used = 0;         // alignments in the stage / already handed out
+    uint32_t pool_n = 0;
+
+    auto flush = [&]() {
+        __threadfence_block();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters->n_records, (unsigned long long)pool_n);
+        base = __shfl(base, 0);
+        for (uint32_t k = lane; k < pool_n; k += 64) {
+            const uint64_t idx = base + k;
+            if (idx < capacity) {
+                uint4 it = my_item[k];
+                it.w = (uint32_t)idx;
+                items[idx] = it;
+                pays[idx] = my_pay[k];
+                digs[idx] = (uint8_t)it.x;
+                kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+            }
+        }
+        __threadfence_block();
+        pool_n = 0;
+    };
+
+    // ---- per-lane state of the alignment being walked
+    bool active = false, warm = false, pending = false, redo = false;
+    bool fin = false;                             // the waiting junction is the alignment's last: it sits in the
+                                                  // walk's own registers, not in the snapshot
+    uint64_t my_i = 0;                            // alignment index in the batch
+    uint32_t pos32 = 0, meta = 0, rank = 0;       // meta: strand | cat << 8 | read_rejected << 10
+    uint32_t left = 0;                            // ops not yet applied
+    uint32_t off0 = 0;                            // first word of the alignment's CIGAR
+    uint64_t wpos = 0;                            // word index of ring[0].x at the top of the loop
+    uint4 ring[LONG_RING];
+#pragma unroll
+    for (uint32_t k = 0; k < LONG_RING; ++k) ring[k] = make_uint4(0, 0, 0, 0);
+    uint32_t state = ST_LIMBO;
+    uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;          // offsets from the alignment's pos
+    uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
+    uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;   // snapshot of a finished junction
+
+    // junction_qc, junctions_extractor.cc:392-397, on a snapshot (offsets are exact and ordered)
+    auto snap_ok = [&]() {
+        const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
+        const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
+        const uint32_t ilen = q_ie - q_is;
+        return !(meta & 0x400u) && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
+               (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
+               (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
+    };
+
+    // ---- one op per active lane, written as selects: branches on per-lane conditions cost more than
+    // the few operations they would skip
+    auto step = [&](uint32_t w) {
+        const bool run = active && left != 0;
+        const uint32_t op = w & 0xfu, len = w >> 4;
+        // BAM_CIGAR_STR "MIDNSHP=XB": M0 I1 D2 N3 S4 H5 P6 =7 X8 B9; classes 1 = M/=/X, 2 = N, 4 = I/D, 8 = S/H
+        const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
+        const bool c_m = run && (cls & 1u), c_n = run && (cls & 2u), c_id = run && (cls & 4u), c_sh = run && (cls & 8u);
+        const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
+        // I/D :257-275: counters first, then the test
+        lind += (c_id && in_l) ? len : 0u;
+        rind += (c_id && in_r) ? len : 0u;
+        const uint32_t indel2 = cur_indel + len;
+        const bool over = c_id && indel2 > p.max_anchor_indel_size;
+        // the op ends a junction: N :208-229, S/H :306-311, I/D beyond the limit
+        const bool trig = in_r && (c_n || c_sh || over);
+        const bool last = run && left == 1;                             // finish() :278-282 follows this op
+
+        // ---- store waiting snapshots: when one is about to be overwritten or orphaned, or enough wait
+        const unsigned long long pm = __ballot(pending);
+        if (pm && (__ballot(pending && (trig || last || !active)) || __popcll(pm) >= (int)LONG_DRAIN)) {
+            const bool pass = pending && snap_ok();
+            const unsigned long long em = __ballot(pass);
+            if (pass) {
+                const uint32_t slot = pool_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                const unsigned long long ri = base_read_index + my_i;
+                if (ordinal <= IPX_ORD_MAX_ORDINAL) {
+                    ReadCtx c;
+                    c.pos = 0; c.rank = rank; c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_index = ri;
+                    uint4 it, pay;
+                    const Rec r{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
+                                (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
+                    pack_record_rel(p, c, r, pos32, ordinal, it, pay);
+                    my_item[slot] = it;
+                    my_pay[slot] = pay;
+                }
+                if (++ordinal > IPX_ORD_MAX_ORDINAL) {
+                    const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 1u;
+                    my_err = e < my_err ? e : my_err;
+                }
+            }
+            pending = false;
+            fin = false;
+            pool_n += (uint32_t)__popcll(em);
+            if (pool_n > LONG_POOL - 64) flush();
+        }
+        s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
+        s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
+        pending = pending || trig;
+
+        // ---- apply the op
+        const uint32_t tpn = tp + len;
+        const bool adv = c_m || c_n || (c_id && op == 2);               // M = X N D move along the reference
+        const bool carry = adv && tpn < tp;
+        const bool bad = run && cls == 0;
+        if (__ballot(carry || bad)) {                                    // rare, wave-uniform
+            if (carry) {                                                 // offsets leave 32 bits: 64-bit re-run
+                if (trig) pending = false;                               // this op's junction comes from the re-run too
+                redo = true;
+            } else if (bad) {                                            // :312-313: the exception ends the read
+                const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
+                const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
+                const unsigned long long e = ((base_read_index + my_i) << IPX_ORD_SHIFT_READ) |
+                                             ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
+                                             (IPX_ERRK_CIGAR << 8) | ch;
+                my_err = e < my_err ? e : my_err;
+            }
+        }
+        const bool n_r = c_n && in_r;                                   // N closes a junction's right anchor ...
+        const bool n_lr = c_n && (in_l || in_r);                        // ... and opens the next intron
+        const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
+        const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
+        const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
+        is = n_lr ? tp : is;
+        as = as2;
+        ie = ie2;
+        ae = c_m ? tpn : ae;
+        uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);               // M from LIMBO zeroes the mismatch counters
+        uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;                    // only: indel counters keep their value
+        lind = n_r ? rind : lind;
+        rind = n_r ? 0u : rind;
+        state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
+        const bool x = c_m && op == 8;                                  // state is LEFT or RIGHT after an M
+        lmm2 += (x && state == ST_LEFT) ? len : 0u;
+        rmm2 += (x && state == ST_RIGHT) ? len : 0u;
+        lmm = lmm2;
+        rmm = rmm2;
+        cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
+        tp = adv ? tpn : tp;
+        // finish(): the alignment's last op leaves a right anchor open (never together with `trig`: an op
+        // that ends a junction does not leave the walk in RIGHT).  The lane stops here, so the junction
+        // stays where it is until the next drain -- which is the next step's, the lane being inactive
+        fin = last && !carry && !bad && state == ST_RIGHT;
+        pending = pending || fin;
+        left -= run ? 1u : 0u;
+        active = run && !last && !carry && !bad;
+    };
+
+    for (;;) {
+        // ---- 64-bit re-run of alignments whose offsets left 32 bits (after their snapshot is stored)
+        if (__ballot(redo && !pending)) {
+            if (redo && !pending) {
+                ReadCtx c;
+                c.pos = (int32_t)pos32; c.flag = 0; c.nhc = 0; c.rank = rank;
+                c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
+                c.read_index = base_read_index + my_i;
+                (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, digs, kb,
+                                  my_err, nullptr, &counters->n_records);
+                redo = false;
+            }
+        }
+        // ---- hand out alignments
+        const unsigned long long idle = __ballot(!active && !warm && !pending && !redo);
+        if (idle) {
+            if (next >= range_end) {
+                if (idle == ~0ull) break;
+            } else {
+                if (staged_used == staged) {
+                    // stage the next 64 alignments: process_alignment gate (junctions_extractor.cc:533-536),
+                    // strand, category, and the first chunks of the CIGAR
+                    const uint64_t rem = range_end - next;
+                    staged = rem < 64 ? (uint32_t)rem : 64u;
+                    staged_used = 0;
+                    if (lane < staged) {
+                        const uint64_t i = next + lane;
+                        const int32_t tid = a_tid[i];
+                        uint32_t nc = a_nc[i];
+                        const uint32_t flag = a_flag[i];
+                        const unsigned long long ri = base_read_index + i;
+                        if (nc <= 1 || tid < 0 || (flag & (F_QCFAIL | F_DUP))) nc = 0;
+                        if (nc && (uint32_t)tid >= p.n_targets) {
+                            const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
+                            my_err = e < my_err ? e : my_err;
+                            nc = 0;
+                        }
+                        const uint32_t off = nc ? a_off[i] : 0u;
+                        if (nc && (uint64_t)off + nc > n_words) {            // words outside the batch
+                            const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
+                            my_err = e < my_err ? e : my_err;
+                            nc = 0;
+                        }
+                        stage.nc[lane] = nc;
+                        if (nc) {
+                            const uint32_t nhc = a_nh[i], xs = a_xs[i];
+                            const uint32_t strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(flag, p.strandness)
+                                                                                     : (xs ? xs : (uint32_t)'.');
+                            const uint32_t rej = ((flag & F_SECONDARY) || (p.exclude_multi && nhc == 2)) ? 0x400u : 0u;
+                            stage.pos[lane] = (uint32_t)a_pos[i];
+                            stage.meta[lane] = strand | (read_category(flag, nhc) << 8) | rej;
+                            stage.rank[lane] = rank_of_tid[tid];
+                            stage.off[lane] = off;
+                        }
+                    }
+                    __threadfence_block();
+                }
+                const uint32_t avail = staged - staged_used;
+                if (!active && !warm && !pending && !redo) {
+                    const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (e < avail) {
+                        const uint32_t k = staged_used + e;
+                        const uint32_t nc = stage.nc[k];
+                        if (nc) {
+                            my_i = next + e;
+                            pos32 = stage.pos[k];
+                            meta = stage.meta[k];
+                            rank = stage.rank[k];
+                            off0 = stage.off[k];
+                            wpos = (uint64_t)off0 - 4 * LONG_RING;        // this turn's refills fetch chunks 0..LONG_RING-1
+                            left = nc;
+                            state = ST_LIMBO;
+                            tp = as = is = ie = ae = 0;
+                            lmm = rmm = lind = rind = cur_indel = ordinal = 0;
+                            warm = true;
+                        }
+                    }
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t took = want < avail ? want : avail;
+                staged_used += took;
+                next += took;
+            }
+        }
+        // ---- 4 * LONG_RING ops; slot k is refilled LONG_RING - 1 chunks ahead of its next use
+#pragma unroll
+        for (uint32_t k = 0; k < LONG_RING; ++k) {
+            const uint4 q = ring[k];
+            step(q.x);
+            step(q.y);
+            step(q.z);
+            step(q.w);
+            // `left` counts from the first word of slot k + 1 now (from the alignment's first word if warm)
+            const bool need = (active && left > 4 * (LONG_RING - 1)) || (warm && left > 4 * k);
+            ring[k] = load4(need ? wpos + 4 * (k + LONG_RING) : (uint64_t)off0);
+        }
+        wpos += 4 * LONG_RING;
+        active = active || warm;
+        warm = false;
+    }
+    if (pool_n) flush();
+
+    unsigned long long e = my_err;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(e, d);
+        e = o < e ? o : e;
+    }
+    if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+
+    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const uint32_t o = __shfl_xor(v[k], dlt);
+            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
+        }
+        if (lane == 0) kb_s[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (t < 6) {
+        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        if (t < 3) {
+            const uint32_t o = x0 | x1 | x2 | x3;
+            if (o) atomicOr(&counters->key_or[t], o);
+        } else {
+            const uint32_t a = x0 & x1 & x2 & x3;
+            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
@@ -398,7 +799,7 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
                            uint64_t capacity, Counters *counters) {
     if (b.n_alignments == 0) return hipSuccess;
     // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
-    const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;
+    const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;      // (the long kernel needs >= 8 words)
     const uint64_t per_tile = short_reads ? 512 : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
     if (blocks > 256ull * 16) blocks = 256ull * 16;
@@ -406,10 +807,26 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
         hipLaunchKernelGGL((k_scan<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
-    else
-        hipLaunchKernelGGL((k_scan<1, 0>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
-                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
+    else {
+        // long CIGARs: waves work through ranges of >= 64 alignments
+        static const uint32_t min_range = [] {
+            const char *e = getenv("IPX_LONG_RANGE");
+            const long v = e ? atol(e) : 0;
+            return (uint32_t)(v >= 64 && v <= 65536 ? v : 64);
+        }();
+        const uint64_t max_waves = 256ull * 3 * 4;      // all resident at once (VGPRs: 3 waves per SIMD)
+        uint64_t per_wave = ipx_div_up(b.n_alignments, max_waves);
+        if (per_wave < min_range) per_wave = min_range;
+        // few alignments per lane: whole multiples of 64, or one lane's second alignment doubles the wave's time
+        if (per_wave < 256) per_wave = (per_wave + 63) / 64 * 64;
+        const uint64_t waves = ipx_div_up(b.n_alignments, per_wave);
+        // the Counters allocation is 256 bytes; bytes 128..191 hold the copy of the array's last words
+        uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + 128);
+        hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
+        hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
+                           b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
+                           b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+    }
     ipx_prof_mark(s, IPXK_SCAN);
     return hipGetLastError();
 }

@@ -133,3 +133,37 @@ def compare_tables(dev, ora, genome_fetch=None):
             fetch = (lambda i=i: genome_fetch(int(dev["target"][i]), int(dev["intron_start"][i]), int(dev["intron_end"][i])))
         got = motif_string(int(dev["strand"][i]), int(dev["motif"][i]), fetch)
         assert got == exp, "splice sites differ for row %d: %r vs %r" % (r, got, exp)
+
+
+def fuzz_batch(n, seed, min_ops, max_ops, n_targets=2, bad_ops=False):
+    """Random CIGARs over every operation the reference knows (MIDNSH=X, optionally P/B): no
+    biological structure, so runs like `N N`, `N D N`, `S` in the middle or an `I` at the start
+    all occur.  Positions are drawn from a few hundred anchors so that junctions repeat."""
+    rng = np.random.default_rng(seed)
+    ops_all = np.array([0, 0, 0, 0, 1, 2, 3, 3, 3, 4, 5, 7, 8], np.uint32)
+    words, offs, ncs = [], [], []
+    total = 0
+    anchors = rng.integers(1000, 2_000_000, 300)
+    intron_lens = np.array([30, 70, 75, 100, 250, 1000, 40_000, 499_999, 500_001], np.uint32)
+    for i in range(n):
+        k = int(rng.integers(min_ops, max_ops + 1))
+        op = ops_all[rng.integers(0, len(ops_all), k)]
+        ln = rng.integers(1, 40, k).astype(np.uint32)
+        is_n = op == 3
+        ln[is_n] = intron_lens[rng.integers(0, len(intron_lens), int(is_n.sum()))]
+        small = (op == 1) | (op == 2)
+        ln[small] = rng.integers(1, 6, int(small.sum()))
+        if bad_ops and i % 97 == 50:
+            op[rng.integers(0, k)] = 6 if i % 2 else 9
+        offs.append(total)
+        ncs.append(k)
+        words.append((ln << np.uint32(4)) | op)
+        total += k
+    flags = np.array([0, 16, 99, 147, 83, 163, 256, 2048, 1024, 512], np.uint16)
+    return {"tid": rng.integers(-1, n_targets, n).astype(np.int32),
+            "pos": anchors[rng.integers(0, len(anchors), n)].astype(np.int32),
+            "flag": flags[np.minimum(rng.integers(0, 40, n), len(flags) - 1) * (rng.random(n) < 0.4)],
+            "xs": np.array([0, ord("+"), ord("-")], np.uint8)[rng.integers(0, 3, n)],
+            "nh": rng.integers(0, 3, n).astype(np.uint8),
+            "cigar_off": np.array(offs, np.uint32), "n_cigar": np.array(ncs, np.uint32),
+            "cigar": np.concatenate(words) if words else np.zeros(0, np.uint32)}

@@ -275,6 +275,66 @@ def test_empty_and_degenerate_inputs():
     ex.close()
 
 
+@pytest.mark.parametrize("ops", [(2, 9), (17, 40), (30, 400)])
+@pytest.mark.parametrize("max_indel", [0, 4, 36])
+def test_random_cigars_match_oracle(ops, max_indel):
+    """CIGARs without biological structure through the short-CIGAR kernel (2-9 ops) and the
+    long-CIGAR kernel (more than 16 ops per alignment on average)."""
+    n = 6000 if ops[1] < 100 else 1500
+    batch = helpers.fuzz_batch(n, seed=61 + ops[0], min_ops=ops[0], max_ops=ops[1])
+    dev, ora, err = _run_both(batch, ["chrB", "chrA"], {"max_anchor_indel_size": max_indel, "min_anchor_length": 3,
+                                                      "min_intron_length": 70})
+    assert err is None
+    assert len(ora["intron_start"]) > 20
+    helpers.compare_tables(dev, ora)
+    # the same through three pushes
+    dev3, _, _ = _run_both(batch, ["chrB", "chrA"], {"max_anchor_indel_size": max_indel, "min_anchor_length": 3,
+                                                    "min_intron_length": 70}, n_push=3)
+    helpers.compare_tables(dev3, ora)
+
+
+def test_long_cigar_kernel_errors_and_wide_offsets():
+    """The long-CIGAR kernel walks 32-bit offsets from the alignment's position; alignments whose
+    offsets leave 32 bits are finished by the 64-bit walk.  Both must agree with the oracle's
+    int64 arithmetic, including the records that precede the wide part."""
+    from intronprospector_amd import synth
+    big = "268435455"                       # 2^28 - 1, the longest op BAM can hold
+    filler = "5M1I" * 12                    # keeps the batch in the long-CIGAR kernel
+    cases = [
+        # fused intron of 2^32 + 1000 bases: rejected (a 32-bit difference would read 1000 and pass)
+        filler + "20M100N20M" + (big + "N") * 16 + "1016N" + "20M",
+        # left anchor of 2^32 + 5 bases: kept (a 32-bit difference would read 5 and fail min-anchor 8)
+        filler + "20M100N20M" + (big + "M") * 16 + "1M100N30M",
+        # wide offsets reached inside deletions; junctions before and after
+        filler + "20M100N20M" + (big + "D") * 17 + "20M200N20M300N25M",
+        # the carrying op itself ends a junction
+        filler + "20M100N" + (big + "M") * 15 + "268435000M" + "5000N" + "20M",
+    ]
+    p = {"max_anchor_indel_size": 0xffffffff, "min_intron_length": 70, "max_intron_length": 0xffffffff}
+    for cig in cases:
+        for pos in (1000, 2_000_000_000):
+            rd = _one_read(_cig(cig), pos=pos)
+            assert len(rd["cigar"]) > 16
+            dev, ora, err = _run_both(rd, ["chr1"], p)
+            assert err is None
+            helpers.compare_tables(dev, ora)
+    # several such alignments among ordinary long ones
+    batch, names, _ = synth.long_reads(300, seed=71, n_targets=2, target_len=9_000_000, n_transcripts=20)
+    # (each at its own position: where two alignments that END beyond 2^32 share a junction, the
+    # reference compares a 64-bit anchor with the stored 32-bit one, see DESIGN.md "Limits")
+    mixed = synth.concat_batches([synth.slice_batch(batch, 0, 100), _one_read(_cig(cases[1]), pos=5000),
+                                  synth.slice_batch(batch, 100, 250), _one_read(_cig(cases[2]), tid=1),
+                                  _one_read(_cig(cases[3]), pos=9000), synth.slice_batch(batch, 250, 300)])
+    dev, ora, err = _run_both(mixed, names, {"max_anchor_indel_size": 36})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+    # earliest error in input order, with the number of records before it
+    bad = helpers.fuzz_batch(1200, seed=72, min_ops=20, max_ops=60, bad_ops=True)
+    dev, ora, err = _run_both(bad, ["chr1", "chr2"], {"max_anchor_indel_size": 4})
+    assert err is not None and dev["error"].kind == 1
+    assert dev["error"].read_index == err.index and dev["error"].detail == err.msg
+
+
 def test_per_operation_scan_kernel_matches_oracle(monkeypatch):
     """ipx_scan_ops.hip (one lane per CIGAR operation, IPX_SCAN=ops) against the oracle on short,
     long and quirk inputs; it must also fall back cleanly on a CIGAR array that is not laid out

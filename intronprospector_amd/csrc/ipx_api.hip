@@ -105,7 +105,11 @@ struct ipx_handle {
     uint64_t reserved_records = 0;
     bool force_lane_scan = true;   // false with IPX_SCAN=ops in the environment: try ipx_scan_ops.hip first
     unsigned long long err_word_host = IPX_ERRW_NONE;
-    bool digs_stale = false;     // dig_a no longer holds digit 0 of items_a (after a sort)
+    bool digs_stale = false;     // dig_a no longer holds the first-pass digits of items_a (after a sort)
+    // Key bits of the digit bytes that scan / adopt write next to the records.  Fixed while the handle
+    // holds records; an empty handle takes `first_hint`: the window the last sort would have liked
+    // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
+    DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
     DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2, d_xchg;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
@@ -464,6 +468,8 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     sp.exclude_multi = (h->params.excludes & IPX_EXCLUDE_MULTI) ? 1u : 0u;
     sp.n_targets = (uint32_t)h->names.size();
     sp.key = h->key;
+    if (h->n_records == 0) h->first_window = h->first_hint;
+    sp.first = h->first_window;
 
     ProfScope prof_scope(&h->prof);
     // state to return to if a scan has to be repeated
@@ -559,17 +565,23 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         const uint64_t sums1 = ipx_div_up(chunks, 4096) + 2;
         const size_t ws_bytes = std::max(ipx_sort_workspace_bytes(R),
                                          (size_t)((2 * chunks_al + sums1) * sizeof(uint32_t) + 1024));
-        // one pass per (up to) 8 bits on which the keys differ (OR ^ AND); bits 0..7 always run first:
-        // their digit bytes come with the records
+        // one pass per (up to) 8 bits on which the keys differ (OR ^ AND).  The digit bytes that came
+        // with the records serve the first pass if their window holds the lowest varying bits;
+        // otherwise the first pass reads its digits from the records
         const uint32_t vary[3] = {h->key_or[0] ^ h->key_and[0], h->key_or[1] ^ h->key_and[1],
                                   h->key_or[2] ^ h->key_and[2]};
-        const SortPlan plan = ipx_plan_sort(vary, h->key.total_bits, true);
+        const SortPlan ideal = ipx_plan_sort(vary, h->key.total_bits, nullptr);
+        const bool bytes_ok = !h->digs_stale && ipx_window_is_first(vary, h->key.total_bits, h->first_window);
+        const SortPlan with_bytes = ipx_plan_sort(vary, h->key.total_bits, &h->first_window);
+        const bool use_bytes = bytes_ok && with_bytes.n <= ideal.n;
+        const SortPlan plan = use_bytes ? with_bytes : ideal;
+        h->first_hint = ideal.digits[0];
         if (resort) {
             if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
             if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
             if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
             HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
-                                   h->dig_b.as<uint8_t>(), !h->digs_stale, R, plan, h->sort_ws.p, h->sort_ws.cap));
+                                   h->dig_b.as<uint8_t>(), use_bytes, R, plan, h->sort_ws.p, h->sort_ws.cap));
             // the records now live (sorted) in one of the two buffers; keep that one as items_a
             // so that later pushes append to, and later sorts start from, a full copy
             if (plan.n & 1u) {
@@ -654,7 +666,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         if (n_valid) {
             // creation-order keys: only the bits on which they differ (OR ^ AND, small[3..6]) need passes
             const uint32_t rvary[3] = {small[3] ^ small[5], small[4] ^ small[6], 0u};
-            const SortPlan rp = ipx_plan_sort(rvary, 64, false);
+            const SortPlan rp = ipx_plan_sort(rvary, 64, nullptr);
             HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
                                    ipx_sort_workspace_bytes(J), IPXK_RANK_SORT));
             HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));
@@ -910,13 +922,14 @@ int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n
     // the handle's own records are replaced
     h->n_records = 0;
     h->digs_stale = false;
+    h->first_window = h->first_hint;
     int rc = reset_counters(h);
     if (rc) return rc;
     if ((rc = grow_records(h, n))) return rc;
     ProfScope prof_scope(&h->prof);
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     HIPCHK(ipx_launch_adopt(h->stream, (const uint4 *)records, n, 0, h->items_a.as<uint4>(), h->pays.as<uint4>(),
-                            h->dig_a.as<uint8_t>(), h->counters.as<Counters>()));
+                            h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>()));
     HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->prof.collect();

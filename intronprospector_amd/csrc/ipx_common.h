@@ -52,12 +52,18 @@ struct KeyLayout {
     uint32_t total_bits, n_digits;              // 8-bit digits
 };
 
+// One radix pass looks at up to 8 key bits taken from at most two runs of bits:
+// digit = bits [lo1, lo1+w1) | bits [lo2, lo2+w2) << w1   (w1 + w2 <= 8, lo2 >= lo1 + w1).
+struct DigitSpec {
+    uint32_t lo1, w1, lo2, w2;
+};
 struct ScanParams {
     uint32_t min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length;
     int32_t strandness;
     uint32_t exclude_multi;
     uint32_t n_targets;
     KeyLayout key;
+    DigitSpec first;      // window of the digit bytes written next to the records (the first sort pass)
 };
 
 // device-side counters of one handle (one cache line apart is not needed: they
@@ -69,25 +75,21 @@ struct Counters {
     uint32_t pad[2];                   // [0]: ipx_scan_ops met a CIGAR layout it cannot walk
 };
 
-// One radix pass looks at up to 8 key bits taken from at most two runs of bits:
-// digit = bits [lo1, lo1+w1) | bits [lo2, lo2+w2) << w1   (w1 + w2 <= 8, lo2 >= lo1 + w1).
-struct DigitSpec {
-    uint32_t lo1, w1, lo2, w2;
-};
 // passes of a sort, least significant first
 struct SortPlan {
     DigitSpec digits[16];
     uint32_t n;
 };
 // Passes that cover exactly the bits set in vary[0..2] (bits on which the keys differ), at most
-// max_bits of them.  first_byte: the first pass is bits 0..7 whatever varies there (its digit bytes
-// were written together with the records).
-static inline SortPlan ipx_plan_sort(const uint32_t vary[3], uint32_t max_bits, bool first_byte) {
+// max_bits of them.  first: a window that is to be the first pass whatever varies in it (its digit
+// bytes were written together with the records), or NULL.  The caller checks with
+// ipx_window_is_first() that no varying bit below the window's top lies outside it.
+static inline SortPlan ipx_plan_sort(const uint32_t vary[3], uint32_t max_bits, const DigitSpec *first) {
     SortPlan plan{};
     uint32_t bit = 0;
-    if (first_byte) {
-        plan.digits[plan.n++] = DigitSpec{0, 8, 0, 0};
-        bit = 8;
+    if (first) {
+        plan.digits[plan.n++] = *first;
+        bit = first->w2 ? first->lo2 + first->w2 : first->lo1 + first->w1;
     }
     auto varies = [&](uint32_t b) { return b < max_bits && ((vary[b >> 5] >> (b & 31u)) & 1u); };
     while (bit < max_bits && plan.n < 16) {
@@ -109,6 +111,30 @@ static inline SortPlan ipx_plan_sort(const uint32_t vary[3], uint32_t max_bits, 
     if (plan.n == 0) plan.digits[plan.n++] = DigitSpec{0, 8, 0, 0};
     return plan;
 }
+// May window d be the least significant pass?  (every varying bit below its top is inside it)
+static inline bool ipx_window_is_first(const uint32_t vary[3], uint32_t max_bits, const DigitSpec &d) {
+    const uint32_t top = d.w2 ? d.lo2 + d.w2 : d.lo1 + d.w1;
+    for (uint32_t b = 0; b < top && b < max_bits; ++b) {
+        const bool inside = (b >= d.lo1 && b < d.lo1 + d.w1) || (d.w2 && b >= d.lo2 && b < d.lo2 + d.w2);
+        if (!inside && ((vary[b >> 5] >> (b & 31u)) & 1u)) return false;
+    }
+    return true;
+}
+#ifdef __HIPCC__
+// bits [lo, lo+w) of the 96-bit key (w <= 8)
+__device__ __forceinline__ uint32_t ipx_key_bits(const uint4 &it, uint32_t lo, uint32_t w) {
+    const uint32_t word = lo >> 5, sh = lo & 31u;
+    const uint32_t w0 = word == 0 ? it.x : (word == 1 ? it.y : it.z);
+    const uint32_t w1 = word == 0 ? it.y : (word == 1 ? it.z : 0u);
+    const uint64_t both = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    return (uint32_t)(both >> sh) & ((1u << w) - 1u);
+}
+__device__ __forceinline__ uint32_t ipx_digit_of(const uint4 &it, const DigitSpec &d) {
+    uint32_t v = ipx_key_bits(it, d.lo1, d.w1);
+    if (d.w2) v |= ipx_key_bits(it, d.lo2, d.w2) << d.w1;
+    return v;
+}
+#endif
 
 struct GenomeDev {
     const uint32_t *twobit;      // 16 bases per word, all sequences concatenated (word aligned per sequence)
@@ -190,4 +216,4 @@ hipError_t ipx_launch_partition_scatter(hipStream_t s, const uint4 *items, const
                                         unsigned long long *cursors /* device, n_parts: start offsets */,
                                         uint4 *out_records /* 2 uint4 per record */);
 hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
-                            uint4 *pays, uint8_t *digs, Counters *counters);
+                            uint4 *pays, uint8_t *digs, DigitSpec first, Counters *counters);

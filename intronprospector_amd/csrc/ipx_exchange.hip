@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ 
 // OR/AND of the keys
 __global__ __launch_bounds__(256) void k_adopt(const uint4 *__restrict__ rec, uint64_t n, uint64_t first_index,
                                                uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                               uint8_t *__restrict__ digs, Counters *counters) {
+                                               uint8_t *__restrict__ digs, DigitSpec first, Counters *counters) {
     __shared__ uint32_t kb_s[4][6];
     uint32_t v[6] = {0u, 0u, 0u, ~0u, ~0u, ~0u};
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_adopt(const uint4 *__restrict__ rec, ui
         it.w = (uint32_t)idx;
         items[idx] = it;
         pays[idx] = rec[2 * i + 1];
-        digs[idx] = (uint8_t)it.x;
+        digs[idx] = (uint8_t)ipx_digit_of(it, first);
         v[0] |= it.x; v[1] |= it.y; v[2] |= it.z;
         v[3] &= it.x; v[4] &= it.y; v[5] &= it.z;
     }
@@ -166,12 +166,12 @@ hipError_t ipx_launch_partition_scatter(hipStream_t s, const uint4 *items, const
 }
 
 hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
-                            uint4 *pays, uint8_t *digs, Counters *counters) {
+                            uint4 *pays, uint8_t *digs, DigitSpec first, Counters *counters) {
     if (!n) return hipSuccess;
     uint64_t blocks = ipx_div_up(n, 2048);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adopt, dim3((uint32_t)blocks), dim3(256), 0, s, records, n, first_index, items, pays, digs,
-                       counters);
+                       first, counters);
     ipx_prof_mark(s, IPXK_ADOPT);
     return hipGetLastError();
 }

@@ -124,7 +124,7 @@ __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx 
     it.w = (uint32_t)idx;
     items[idx] = it;
     pays[idx] = pay;
-    digs[idx] = (uint8_t)it.x;                     // digit 0 for the first sort pass
+    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);  // digit of the first sort pass
     kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
     kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
 }
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t
                         it.w = (uint32_t)idx;
                         items[idx] = it;
                         pays[idx] = pool_pay[k];
-                        digs[idx] = (uint8_t)it.x;
+                        digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
                         kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                         kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
                     }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
                 it.w = (uint32_t)idx;
                 items[idx] = it;
                 pays[idx] = my_pay[k];
-                digs[idx] = (uint8_t)it.x;
+                digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
                 kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                 kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
             }

@@ -332,9 +332,10 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
                 }
                 const unsigned long long order = ((a.base_read_index + rid) << IPX_ORD_SHIFT_READ) |
                                                  ((unsigned long long)ord << IPX_ORD_SHIFT_ORDINAL) | (r_strand << 2) | cat;
-                a.items[idx] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)idx);
+                const uint4 it = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)idx);
+                a.items[idx] = it;
                 a.pays[idx] = make_uint4((uint32_t)order, (uint32_t)(order >> 32), r_pos + r_as, r_pos + r_ae);
-                a.digs[idx] = (uint8_t)lo;
+                a.digs[idx] = (uint8_t)ipx_digit_of(it, a.p.first);
                 kb[0] |= (uint32_t)lo; kb[1] |= (uint32_t)(lo >> 32); kb[2] |= (uint32_t)hi;
                 kb[3] &= (uint32_t)lo; kb[4] &= (uint32_t)(lo >> 32); kb[5] &= (uint32_t)hi;
             }

@@ -29,19 +29,7 @@ constexpr uint32_t SORT_IPT = 8;                        // items per thread
 constexpr uint32_t SORT_TILE = SORT_THREADS * SORT_IPT; // 2048 items = 32 KiB
 constexpr uint32_t SCAN_TILE = 4096;
 
-// bits [lo, lo+w) of the 96-bit key (w <= 8)
-__device__ __forceinline__ uint32_t key_bits(const uint4 &it, uint32_t lo, uint32_t w) {
-    const uint32_t word = lo >> 5, sh = lo & 31u;
-    const uint32_t w0 = word == 0 ? it.x : (word == 1 ? it.y : it.z);
-    const uint32_t w1 = word == 0 ? it.y : (word == 1 ? it.z : 0u);
-    const uint64_t both = (uint64_t)w0 | ((uint64_t)w1 << 32);
-    return (uint32_t)(both >> sh) & ((1u << w) - 1u);
-}
-__device__ __forceinline__ uint32_t digit_of(const uint4 &it, const DigitSpec &d) {
-    uint32_t v = key_bits(it, d.lo1, d.w1);
-    if (d.w2) v |= key_bits(it, d.lo2, d.w2) << d.w1;
-    return v;
-}
+__device__ __forceinline__ uint32_t digit_of(const uint4 &it, const DigitSpec &d) { return ipx_digit_of(it, d); }
 
 // per-tile digit histogram; BYTES: from the digit-byte stream, else from the items.
 // A block walks several tiles (the per-tile work is tiny: launch cost would dominate).

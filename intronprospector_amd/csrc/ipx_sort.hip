@@ -33,50 +33,72 @@ __device__ __forceinline__ uint32_t digit_of(const uint4 &it, const DigitSpec &d
 
 // per-tile digit histogram; BYTES: from the digit-byte stream, else from the items.
 // A block walks several tiles (the per-tile work is tiny: launch cost would dominate).
-template <bool BYTES>
+// A block counts GROUP consecutive tiles and then writes, per bin, the group's counts side by side
+// (hist is bin-major: with single tiles a block writes 256 lone 4-byte words).  The group's loads are
+// issued together; small inputs use GROUP = 1 to have enough blocks.
+template <bool BYTES, uint32_t GROUP>
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__ items,
                                                        const uint8_t *__restrict__ digs, uint64_t n,
                                                        DigitSpec d, uint32_t *__restrict__ hist,
                                                        uint32_t n_tiles) {
-    __shared__ uint32_t h[256];
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        h[threadIdx.x] = 0;
-        __syncthreads();
-        const uint64_t base = (uint64_t)tile * SORT_TILE;
-        if (BYTES) {
-            const uint64_t i0 = base + (uint64_t)threadIdx.x * 8;
-            if (i0 + 8 <= n) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(digs + i0);      // tile bases are 2048-aligned
-                // high digits of (nearly) sorted keys: the thread's 8 bytes, often the whole wave's,
-                // are one value -> one LDS add instead of 8 (512) on a single, contended bin
-                const uint32_t b0 = v.x & 0xffu;
-                const bool uni = (v.x == b0 * 0x01010101u) && (v.y == v.x);
-                const uint64_t act = __ballot(1);
-                const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
-                if (__ballot(uni && b0 == first) == act) {
-                    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
-                        atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
-                } else if (uni) {
-                    atomicAdd(&h[b0], 8u);
-                } else {
+    __shared__ uint32_t hs[GROUP][256];
+    const uint32_t n_groups = (n_tiles + GROUP - 1) / GROUP;
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
-                        atomicAdd(&h[(v.x >> (8 * k)) & 0xffu], 1u);
-                        atomicAdd(&h[(v.y >> (8 * k)) & 0xffu], 1u);
+        for (uint32_t g = 0; g < GROUP; ++g) hs[g][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t tile0 = group * GROUP;
+        if (BYTES) {
+            uint2 v[GROUP];
+            bool whole[GROUP];
+#pragma unroll
+            for (uint32_t g = 0; g < GROUP; ++g) {
+                const uint64_t i0 = (uint64_t)(tile0 + g) * SORT_TILE + (uint64_t)threadIdx.x * 8;
+                whole[g] = tile0 + g < n_tiles && i0 + 8 <= n;
+                v[g] = whole[g] ? *reinterpret_cast<const uint2 *>(digs + i0) : make_uint2(0, 0);   // tile bases are 2048-aligned
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < GROUP; ++g) {
+                uint32_t *h = hs[g];
+                if (whole[g]) {
+                    // high digits of (nearly) sorted keys: the thread's 8 bytes, often the whole wave's,
+                    // are one value -> one LDS add instead of 8 (512) on a single, contended bin
+                    const uint32_t b0 = v[g].x & 0xffu;
+                    const bool uni = (v[g].x == b0 * 0x01010101u) && (v[g].y == v[g].x);
+                    const uint64_t act = __ballot(1);
+                    const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
+                    if (__ballot(uni && b0 == first) == act) {
+                        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
+                            atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
+                    } else if (uni) {
+                        atomicAdd(&h[b0], 8u);
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            atomicAdd(&h[(v[g].x >> (8 * k)) & 0xffu], 1u);
+                            atomicAdd(&h[(v[g].y >> (8 * k)) & 0xffu], 1u);
+                        }
                     }
+                } else if (tile0 + g < n_tiles) {
+                    const uint64_t i0 = (uint64_t)(tile0 + g) * SORT_TILE + (uint64_t)threadIdx.x * 8;
+                    for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
                 }
-            } else {
-                for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
             }
         } else {
+            for (uint32_t g = 0; g < GROUP && tile0 + g < n_tiles; ++g) {
+                const uint64_t base = (uint64_t)(tile0 + g) * SORT_TILE;
 #pragma unroll
-            for (uint32_t r = 0; r < SORT_IPT; ++r) {
-                const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
-                if (i < n) atomicAdd(&h[digit_of(items[i], d)], 1u);
+                for (uint32_t r = 0; r < SORT_IPT; ++r) {
+                    const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
+                    if (i < n) atomicAdd(&hs[g][digit_of(items[i], d)], 1u);
+                }
             }
         }
         __syncthreads();
-        hist[(uint64_t)threadIdx.x * n_tiles + tile] = h[threadIdx.x];
+        uint32_t *row = hist + (uint64_t)threadIdx.x * n_tiles + tile0;
+#pragma unroll
+        for (uint32_t g = 0; g < GROUP; ++g)
+            if (tile0 + g < n_tiles) row[g] = hs[g][threadIdx.x];
         __syncthreads();
     }
 }
@@ -323,17 +345,22 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     uint32_t *hist = (uint32_t *)workspace;
     uint32_t *bin_total = hist + (uint64_t)256 * n_tiles;
     const bool bytes = dig_a != nullptr && dig_b != nullptr;
-    const uint32_t hist_grid = n_tiles < 1024 ? n_tiles : 1024;
+    const bool grouped = n_tiles >= 2048;                 // 8 tiles per block once that leaves >= 256 blocks
+    const uint32_t n_groups = grouped ? (n_tiles + 7) / 8 : n_tiles;
+    const uint32_t hist_grid = n_groups < 2048 ? n_groups : 2048;
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
     for (uint32_t k = 0; k < plan.n; ++k) {
         const DigitSpec d = plan.digits[k];
         const bool has_next = k + 1 < plan.n;
         const DigitSpec next_d = has_next ? plan.digits[k + 1] : DigitSpec{0, 8, 0, 0};
-        if (bytes && (k > 0 || first_bytes_valid))
-            hipLaunchKernelGGL(k_hist<true>, dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
-        else
-            hipLaunchKernelGGL(k_hist<false>, dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles);
+        const bool from_bytes = bytes && (k > 0 || first_bytes_valid);
+#define IPX_HIST(B, G) hipLaunchKernelGGL((k_hist<B, G>), dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles)
+        if (from_bytes && grouped) IPX_HIST(true, 8);
+        else if (from_bytes) IPX_HIST(true, 1);
+        else if (grouped) IPX_HIST(false, 8);
+        else IPX_HIST(false, 1);
+#undef IPX_HIST
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_HIST);
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);

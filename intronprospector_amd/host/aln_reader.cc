@@ -1,6 +1,7 @@
 // aln_reader.cc -- see aln_reader.hh.
 #include "aln_reader.hh"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -10,13 +11,23 @@ namespace ipxhost {
 static uint8_t nh_class(long long v) { return v <= 0 ? 0 : (v == 1 ? 1 : 2); }
 
 AlnReader::AlnReader(const std::string &path) : path_(path) {
-    fh_ = gzopen(path.c_str(), "rb");       // transparent for plain text; BGZF is a multi-member gzip file
+    if (BgzfReader::is_bgzf(path)) {
+        bgzf_.reset(new BgzfReader(path));
+        unsigned char magic[4];
+        if (bgzf_->read(magic, 4) == 4 && memcmp(magic, "BAM\1", 4) == 0) {
+            bam_ = true;
+            parse_bam_header();
+            return;
+        }
+        bgzf_.reset();                      // bgzip'd SAM text: a multi-member gzip file to zlib
+    }
+    fh_ = gzopen(path.c_str(), "rb");       // transparent for plain text
     if (!fh_) throw std::runtime_error("Error opening BAM/SAM/CRAM file: " + path);
     gzbuffer(fh_, 1 << 20);
     unsigned char magic[4];
     int n = gzread(fh_, magic, 4);
     if (n == 4 && memcmp(magic, "BAM\1", 4) == 0) {
-        bam_ = true;
+        bam_ = true;                        // BAM in plain gzip or uncompressed: single-threaded
         parse_bam_header();
     } else {
         if (n == 4 && memcmp(magic, "CRAM", 4) == 0)
@@ -130,13 +141,20 @@ bool AlnReader::read_sam(AlnRecord &rec) {
 }
 
 // ---- BAM -----------------------------------------------------------------------
-void AlnReader::read_exact(void *dst, size_t n, const char *what) {
+size_t AlnReader::read_some(void *dst, size_t n) {
+    if (bgzf_) return bgzf_->read(dst, n);
     size_t got = 0;
     while (got < n) {
         int r = gzread(fh_, (char *)dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
-        if (r <= 0) throw std::runtime_error(std::string("Error reader BAM record: ") + path_ + " (" + what + ")");
+        if (r < 0) throw std::runtime_error("Error reader BAM record: " + path_);
+        if (r == 0) break;
         got += (size_t)r;
     }
+    return got;
+}
+
+void AlnReader::read_exact(void *dst, size_t n, const char *what) {
+    if (read_some(dst, n) != n) throw std::runtime_error(std::string("Error reader BAM record: ") + path_ + " (" + what + ")");
 }
 
 static uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -163,7 +181,7 @@ void AlnReader::parse_bam_header() {
 
 bool AlnReader::read_bam(AlnRecord &rec) {
     uint8_t w[4];
-    int r = gzread(fh_, w, 4);
+    const size_t r = read_some(w, 4);
     if (r == 0) return false;
     if (r != 4) throw std::runtime_error("Error reader BAM record: " + path_);
     uint32_t block = le32(w);

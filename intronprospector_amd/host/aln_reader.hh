@@ -11,7 +11,10 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <memory>
 #include <zlib.h>
+
+#include "bgzf_reader.hh"
 
 namespace ipxhost {
 
@@ -35,12 +38,14 @@ public:
     const std::vector<std::string> &target_names() const { return names_; }
     const std::vector<int64_t> &target_lengths() const { return lengths_; }
     bool is_bam() const { return bam_; }
+    unsigned decode_threads() const { return bgzf_ ? bgzf_->threads() : 1; }
     // false at end of input; throws std::runtime_error on a malformed record
     bool read(AlnRecord &rec);
 
 private:
     std::string path_;
-    gzFile fh_ = nullptr;
+    gzFile fh_ = nullptr;                    // SAM text, gzip'd SAM
+    std::unique_ptr<BgzfReader> bgzf_;       // BAM: blocks inflated by a thread pool
     bool bam_ = false;
     std::vector<std::string> names_;
     std::vector<int64_t> lengths_;
@@ -52,6 +57,7 @@ private:
     bool read_sam(AlnRecord &rec);
     // BAM state
     std::vector<uint8_t> buf_;
+    size_t read_some(void *dst, size_t n);
     void read_exact(void *dst, size_t n, const char *what);
     void parse_bam_header();
     bool read_bam(AlnRecord &rec);

@@ -1,0 +1,154 @@
+// bgzf_reader.cc -- see bgzf_reader.hh.
+#include "bgzf_reader.hh"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <zlib.h>
+
+namespace ipxhost {
+
+static const size_t kHeader = 18, kFooter = 8;
+
+static bool bgzf_header_ok(const uint8_t *h) {
+    // gzip magic, deflate, FEXTRA; XLEN >= 6 with the BC subfield first (every writer puts it there)
+    return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+}
+
+bool BgzfReader::is_bgzf(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t h[kHeader];
+    const bool ok = fread(h, 1, kHeader, f) == kHeader && bgzf_header_ok(h);
+    fclose(f);
+    return ok;
+}
+
+BgzfReader::BgzfReader(const std::string &path, unsigned n_threads) : path_(path) {
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_) throw std::runtime_error("Error opening BAM/SAM/CRAM file: " + path);
+    setvbuf(fp_, nullptr, _IOFBF, 1 << 22);
+    if (n_threads == 0) {
+        const char *e = getenv("IPX_DECODE_THREADS");
+        const long v = e ? atol(e) : 0;
+        n_threads = v > 0 ? (unsigned)v : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    n_threads = std::min(n_threads, 64u);
+    ring_.resize((size_t)n_threads * 4);
+    for (unsigned i = 0; i < n_threads; ++i) workers_.emplace_back(&BgzfReader::worker, this);
+}
+
+BgzfReader::~BgzfReader() {
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = true;
+    }
+    can_produce_.notify_all();
+    can_consume_.notify_all();
+    for (auto &t : workers_) t.join();
+    if (fp_) fclose(fp_);
+}
+
+bool BgzfReader::read_block(Slot &s) {
+    uint8_t h[kHeader];
+    const size_t got = fread(h, 1, kHeader, fp_);
+    if (got == 0) return false;
+    if (got != kHeader || !bgzf_header_ok(h)) {
+        s.error = "not a BGZF block";
+        return true;
+    }
+    const size_t xlen = h[10] | (h[11] << 8);
+    const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1;        // whole block
+    if (xlen < 6 || bsize < 12 + xlen + kFooter) {
+        s.error = "bad BGZF block size";
+        return true;
+    }
+    s.in.resize(bsize);
+    memcpy(s.in.data(), h, kHeader);
+    if (fread(s.in.data() + kHeader, 1, bsize - kHeader, fp_) != bsize - kHeader) s.error = "truncated BGZF block";
+    compressed_bytes_ += bsize;
+    return true;
+}
+
+void BgzfReader::worker() {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return;
+    for (;;) {
+        Slot *s;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            can_produce_.wait(lk, [&] { return stop_ || (next_claim_ < end_seq_ && next_claim_ < next_consume_ + ring_.size()); });
+            if (stop_ || next_claim_ >= end_seq_) break;
+            s = &ring_[next_claim_ % ring_.size()];
+            s->error.clear();
+            s->out.clear();
+            if (!read_block(*s)) {                  // end of file: nothing claimed
+                end_seq_ = next_claim_;
+                lk.unlock();
+                can_consume_.notify_all();
+                can_produce_.notify_all();
+                break;
+            }
+            ++next_claim_;
+        }
+        if (s->error.empty()) {
+            const size_t xlen = s->in[10] | (s->in[11] << 8);
+            const uint8_t *foot = s->in.data() + s->in.size() - kFooter;
+            const uint32_t crc = foot[0] | (foot[1] << 8) | (foot[2] << 16) | ((uint32_t)foot[3] << 24);
+            const uint32_t isize = foot[4] | (foot[5] << 8) | (foot[6] << 16) | ((uint32_t)foot[7] << 24);
+            if (isize > 65536) {
+                s->error = "BGZF block larger than 64 KiB";
+            } else {
+                s->out.resize(isize);
+                inflateReset(&zs);
+                zs.next_in = s->in.data() + 12 + xlen;
+                zs.avail_in = (uInt)(s->in.size() - 12 - xlen - kFooter);
+                zs.next_out = s->out.data();
+                zs.avail_out = isize;
+                // (an empty block, like the end-of-file marker, has nothing to inflate into)
+                const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+                if (rc != Z_STREAM_END || zs.avail_out != 0) s->error = "inflate failed";
+                else if ((uint32_t)crc32(crc32(0, nullptr, 0), s->out.data(), isize) != crc) s->error = "CRC mismatch";
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            s->ready = true;
+        }
+        can_consume_.notify_all();
+    }
+    inflateEnd(&zs);
+}
+
+size_t BgzfReader::read(void *dst, size_t n) {
+    size_t done = 0;
+    while (done < n) {
+        Slot &s = ring_[next_consume_ % ring_.size()];
+        if (!cur_valid_) {
+            std::unique_lock<std::mutex> lk(m_);
+            can_consume_.wait(lk, [&] { return s.ready || next_consume_ >= end_seq_ || stop_; });
+            if (!s.ready) break;                    // end of file
+            if (!s.error.empty()) throw std::runtime_error("Error reader BAM record: " + path_ + " (" + s.error + ")");
+            cur_valid_ = true;
+            cur_off_ = 0;
+        }
+        const size_t take = std::min(n - done, s.out.size() - cur_off_);
+        memcpy((char *)dst + done, s.out.data() + cur_off_, take);
+        done += take;
+        cur_off_ += take;
+        if (cur_off_ == s.out.size()) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                s.ready = false;
+                ++next_consume_;
+            }
+            cur_valid_ = false;
+            can_produce_.notify_all();
+        }
+    }
+    return done;
+}
+
+}  // namespace ipxhost

@@ -7,7 +7,14 @@
 //         chrom start end anchor_start anchor_end strand splice_sites(- = none) ijunc c0 c1 c2 nbins cnt...
 //       writes PREFIX.juncs.bed, PREFIX.introns.bed, PREFIX.introns.bed6, PREFIX.introns.tsv with
 //       the output scheduling of src/intronProspector.cc:330-351
+//   ipx_host_check make-bam N OUT.bam
+//       N synthetic 100 bp spliced alignments (aM nN bM, sequence, qualities, NH/XS tags) as a BAM
+//       file, to time the decoder on
+//   ipx_host_check bench-decode FILE [THREADS]
+//       decodes every record; prints records, seconds, records/s and compressed MB/s
+#include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -62,14 +69,111 @@ static int print_table(const std::string &prefix, float min_conf) {
     return 0;
 }
 
+// ---- synthetic BAM (SAM spec 4.2), BGZF blocks of <= 60000 bytes at zlib level 6
+static void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+static void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+
+static void write_bgzf_block(FILE *f, const uint8_t *data, size_t n) {
+    uint8_t out[70000];
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = const_cast<uint8_t *>(data);
+    zs.avail_in = (uInt)n;
+    zs.next_out = out + 18;
+    zs.avail_out = sizeof out - 18 - 8;
+    deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+    memcpy(out, hdr, 16);
+    const size_t bsize = clen + 18 + 8 - 1;
+    out[16] = (uint8_t)bsize;
+    out[17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), data, (uInt)n);
+    uint8_t *ft = out + 18 + clen;
+    for (int i = 0; i < 4; ++i) { ft[i] = (uint8_t)(crc >> (8 * i)); ft[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+    fwrite(out, 1, 18 + clen + 8, f);
+}
+
+static int make_bam(uint64_t n, const char *path) {
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); return 1; }
+    std::vector<uint8_t> buf;
+    auto flush = [&](bool all) {
+        size_t off = 0;
+        while (buf.size() - off >= 60000 || (all && off < buf.size())) {
+            const size_t k = std::min<size_t>(60000, buf.size() - off);
+            write_bgzf_block(f, buf.data() + off, k);
+            off += k;
+        }
+        buf.erase(buf.begin(), buf.begin() + off);
+    };
+    const char *text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:200000000\n";
+    buf.insert(buf.end(), {'B', 'A', 'M', 1});
+    put32(buf, (uint32_t)strlen(text));
+    buf.insert(buf.end(), text, text + strlen(text));
+    put32(buf, 1);
+    put32(buf, 5);
+    buf.insert(buf.end(), {'c', 'h', 'r', '1', 0});
+    put32(buf, 200000000);
+    uint64_t rng = 88172645463325252ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    for (uint64_t i = 0; i < n; ++i) {
+        char name[32];
+        const int ln = snprintf(name, sizeof name, "read%llu", (unsigned long long)i) + 1;
+        const uint32_t a = 10 + (uint32_t)(next() % 80), ilen = 70 + (uint32_t)(next() % 20000), b = 100 - a;
+        const uint32_t pos = (uint32_t)(i * 18 % 190000000);
+        std::vector<uint8_t> r;
+        put32(r, 0); put32(r, pos);
+        r.push_back((uint8_t)ln); r.push_back(60); put16(r, 4681);
+        put16(r, 3); put16(r, (next() & 1) ? 16 : 0); put32(r, 100);
+        put32(r, 0xffffffffu); put32(r, 0xffffffffu); put32(r, 0);
+        r.insert(r.end(), name, name + ln);
+        put32(r, a << 4); put32(r, (ilen << 4) | 3); put32(r, b << 4);
+        for (int k = 0; k < 50; ++k) { const uint64_t x = next(); r.push_back((uint8_t)(((1u << (x & 3)) << 4) | (1u << ((x >> 2) & 3)))); }
+        for (int k = 0; k < 100; ++k) r.push_back((uint8_t)(20 + next() % 21));
+        r.insert(r.end(), {'N', 'H', 'C', 1, 'X', 'S', 'A', (uint8_t)((next() & 1) ? '+' : '-')});
+        put32(buf, (uint32_t)r.size());
+        buf.insert(buf.end(), r.begin(), r.end());
+        if (buf.size() >= (1u << 20)) flush(false);
+    }
+    flush(true);
+    write_bgzf_block(f, nullptr, 0);
+    fclose(f);
+    return 0;
+}
+
+static int bench_decode(const char *path, const char *threads) {
+    if (threads) setenv("IPX_DECODE_THREADS", threads, 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    AlnReader rd(path);
+    AlnRecord r;
+    uint64_t n = 0, words = 0, sum = 0;
+    while (rd.read(r)) {
+        ++n;
+        words += r.cigar.size();
+        sum += (uint64_t)r.pos + r.flag + r.nh + r.xs;
+    }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    const double mb = (double)in.tellg() / 1e6;
+    printf("{\"records\": %llu, \"cigar_words\": %llu, \"seconds\": %.4f, \"records_per_s\": %.0f, \"compressed_MB_per_s\": %.1f, "
+           "\"threads\": %u, \"checksum\": %llu}\n",
+           (unsigned long long)n, (unsigned long long)words, s, n / s, mb / s, rd.decode_threads(), (unsigned long long)sum);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
         if (argc == 3 && std::string(argv[1]) == "dump-aln") return dump_aln(argv[2]);
         if (argc == 4 && std::string(argv[1]) == "print-table") return print_table(argv[2], strtof(argv[3], nullptr));
+        if (argc == 4 && std::string(argv[1]) == "make-bam") return make_bam(strtoull(argv[2], nullptr, 10), argv[3]);
+        if ((argc == 3 || argc == 4) && std::string(argv[1]) == "bench-decode") return bench_decode(argv[2], argc == 4 ? argv[3] : nullptr);
     } catch (const std::exception &e) {
         fprintf(stderr, "Error: %s\n", e.what());
         return 1;
     }
-    fprintf(stderr, "usage: ipx_host_check dump-aln FILE | print-table PREFIX MIN_CONF < table.txt\n");
+    fprintf(stderr, "usage: ipx_host_check dump-aln FILE | print-table PREFIX MIN_CONF < table.txt | make-bam N OUT | bench-decode FILE [THREADS]\n");
     return 2;
 }

@@ -4,6 +4,7 @@ SAM, BAM), and ordering + confidence + writers against the oracle and the refere
 golden files."""
 import ctypes
 import gzip
+import json
 import os
 import re
 import shutil
@@ -93,6 +94,36 @@ def test_bam_long_cigar_in_cg_tag(host_check, tmp_path):
     bam = str(tmp_path / "long.bam")
     bamio.sam_to_bam(str(sam), bam, long_cigar_threshold=10)      # force the CG:B:I path
     assert _dump(host_check, bam) == _dump(host_check, str(sam))
+
+
+def test_bgzf_blocks_inflate_in_parallel_in_file_order(host_check, tmp_path):
+    """host/bgzf_reader.cc: many blocks, 1 / 3 / 8 inflate threads give the same
+    records in the same order; damaged and truncated blocks are reported, not skipped."""
+    bam = str(tmp_path / "many.bam")
+    subprocess.run([host_check, "make-bam", "60000", bam], check=True)          # ~120 BGZF blocks
+    outs = []
+    for t in ("1", "3", "8"):
+        r = subprocess.run([host_check, "dump-aln", bam], stdout=subprocess.PIPE, check=True,
+                           env=dict(os.environ, IPX_DECODE_THREADS=t))
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2]
+    lines = outs[0].decode().splitlines()
+    assert len(lines) == 60001 and lines[0].startswith("@SQ\tchr1")
+    first = lines[1].split("\t")
+    assert first[0] == "0" and first[5] == "3" and all(int(w) & 15 in (0, 3) for w in first[6].split(","))
+    r = subprocess.run([host_check, "bench-decode", bam, "4"], stdout=subprocess.PIPE, check=True)
+    rep = json.loads(r.stdout)
+    assert rep["records"] == 60000 and rep["cigar_words"] == 180000 and rep["threads"] == 4
+    raw = bytearray(open(bam, "rb").read())
+    bad = str(tmp_path / "bad.bam")
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0x55                                                  # inside some block's payload
+    open(bad, "wb").write(flipped)
+    r = subprocess.run([host_check, "dump-aln", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Error reader BAM record" in r.stderr
+    open(bad, "wb").write(raw[:len(raw) // 2])                                     # cut inside a block
+    r = subprocess.run([host_check, "dump-aln", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Error reader BAM record" in r.stderr
 
 
 def _table_text(t, names):

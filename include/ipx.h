@@ -248,6 +248,23 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
                           void *dst_records);
 int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n_alignments);
 
+/* The handle's pending junction records, decoded, in no particular order (sort by `order`
+ * for the order in which the reference would have met them).  For --debug-trace
+ * (src/junctions_extractor.cc:451-457,471-477): the trace is the list of records that a
+ * junction counted, i.e. those with IPX_RECORD_SEQ(order) >= the creator_order of their row
+ * in the table.  dst is host memory with room for `capacity` records; *n_records receives
+ * the number the handle holds (nothing is written if that exceeds capacity). */
+typedef struct ipx_record {
+    uint64_t order;          /* read_index << 30 | ordinal << 10 | read strand << 2 | read category */
+    uint32_t target;         /* as in ipx_table.target */
+    uint32_t intron_start, intron_end, anchor_start, anchor_end;
+    uint32_t read_offset;    /* low 16 bits of intron_start - pos */
+} ipx_record;
+#define IPX_RECORD_SEQ(order) ((order) >> 10)            /* comparable with ipx_table.creator_order */
+#define IPX_RECORD_READ(order) ((order) >> 30)
+#define IPX_RECORD_STRAND(order) ((char)(((order) >> 2) & 0xff))
+int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64_t *n_records);
+
 /* copy between any two of {host, device} on the handle's stream, then wait */
 int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes);
 

@@ -23,7 +23,8 @@ SYMBOLS = [
     "ipx_abi_version", "ipx_create", "ipx_destroy", "ipx_set_targets", "ipx_set_genome_2bit",
     "ipx_reserve", "ipx_push_batch", "ipx_finalize", "ipx_clear", "ipx_last_error",
     "ipx_finalize_shard", "ipx_copy", "ipx_records_pending", "ipx_records_sample",
-    "ipx_records_partition", "ipx_records_adopt", "ipx_last_timing", "ipx_profile", "ipx_profile_read",
+    "ipx_records_partition", "ipx_records_adopt", "ipx_records_export", "ipx_last_timing", "ipx_profile",
+    "ipx_profile_read",
 ]
 
 
@@ -100,6 +101,7 @@ def load():
     lib.ipx_records_sample.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.ipx_records_partition.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     lib.ipx_records_adopt.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
+    lib.ipx_records_export.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ipx_profile.argtypes = [vp, C.c_int]
     lib.ipx_profile_read.argtypes = [vp, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]

@@ -868,6 +868,47 @@ int ipx_records_pending(const ipx_handle *h, uint64_t *n_records) {
     return IPX_OK;
 }
 
+// host-side twin of unpack_key (ipx_common.h)
+static void unpack_key_host(const uint32_t it[4], const KeyLayout &kl, uint32_t &rank, uint32_t &start, uint32_t &end,
+                            uint32_t &off16) {
+    const uint64_t lo = (uint64_t)it[0] | ((uint64_t)it[1] << 32);
+    const uint64_t hi = it[2];
+    off16 = (uint32_t)lo & 0xffffu;
+    const uint32_t len = (uint32_t)((lo >> 16) & ((kl.len_bits >= 32) ? 0xffffffffull : ((1ull << kl.len_bits) - 1)));
+    const uint32_t s1 = 16 + kl.len_bits, s2 = s1 + 32;
+    uint64_t st = lo >> s1;
+    if (s1 > 32) st |= hi << (64 - s1);
+    start = (uint32_t)st;
+    const uint64_t rk = (s2 < 64) ? ((lo >> s2) | (hi << (64 - s2))) : (hi >> (s2 - 64));
+    rank = (uint32_t)(rk & ((kl.rank_bits >= 32) ? 0xffffffffull : ((1ull << kl.rank_bits) - 1)));
+    end = start + len;
+}
+
+int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64_t *n_records) {
+    if (!h || !n_records) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    const uint64_t n = h->n_records;
+    *n_records = n;
+    if (n == 0) return IPX_OK;
+    if (!dst || capacity < n) return IPX_EINVAL;
+    std::vector<uint32_t> items(4 * n), pays(4 * n);
+    HIPCHK(hipMemcpyAsync(items.data(), h->items_a.p, n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pays.data(), h->pays.p, n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t *it = &items[4 * i];
+        const uint32_t *py = &pays[4 * (uint64_t)it[3]];         // item.w = index of the record's payload
+        uint32_t rank;
+        ipx_record &r = dst[i];
+        unpack_key_host(it, h->key, rank, r.intron_start, r.intron_end, r.read_offset);
+        r.target = rank < h->tid_of_rank.size() ? h->tid_of_rank[rank] : rank;
+        r.order = (uint64_t)py[0] | ((uint64_t)py[1] << 32);
+        r.anchor_start = py[2];
+        r.anchor_end = py[3];
+    }
+    return IPX_OK;
+}
+
 int ipx_records_sample(ipx_handle *h, uint32_t n_samples, uint64_t *out_keys) {
     if (!h || (n_samples && !out_keys) || n_samples > 4096) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);

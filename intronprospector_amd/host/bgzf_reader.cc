@@ -32,7 +32,7 @@ BgzfReader::BgzfReader(const std::string &path, unsigned n_threads) : path_(path
     if (n_threads == 0) {
         const char *e = getenv("IPX_DECODE_THREADS");
         const long v = e ? atol(e) : 0;
-        n_threads = v > 0 ? (unsigned)v : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        n_threads = v > 0 ? (unsigned)v : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     }
     n_threads = std::min(n_threads, 64u);
     ring_.resize((size_t)n_threads * 4);

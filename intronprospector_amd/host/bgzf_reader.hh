@@ -22,7 +22,8 @@ class BgzfReader {
 public:
     // does the file start with a BGZF block header?
     static bool is_bgzf(const std::string &path);
-    // n_threads 0: IPX_DECODE_THREADS from the environment, else min(hardware threads, 16)
+    // n_threads 0: IPX_DECODE_THREADS from the environment, else min(hardware threads, 8): beyond that
+    // the single consumer that parses the records is the limit (measured)
     explicit BgzfReader(const std::string &path, unsigned n_threads = 0);
     ~BgzfReader();
     BgzfReader(const BgzfReader &) = delete;

@@ -4,7 +4,7 @@
 // :289-292, the three drivers :356-401, output_junctions :330-351, error exit :63-67.
 //
 // Not offered (outside the accelerated path): --pass-through,
-// --set-XS-strand-tag, --set-TS-strand-tag, --debug-trace.
+// --set-XS-strand-tag, --set-TS-strand-tag.
 #include <getopt.h>
 
 #include <algorithm>
@@ -43,6 +43,7 @@ static const char *usage_msg =
     "  -s, --strandness=UN|RF|FR   -X, --excludes=multi\n"
     "  -g, --genome-fasta=fasta (needs fasta.fai)   -f, --sj-filter=all|canon   -S, --skip-missing-targets\n"
     "  -j, --junction-bed=file   -n, --intron-bed=file   -b, --intron-bed6=file   -c, --intron-calls=file\n"
+    "  -D, --debug-trace=file\n"
     "Outputs whose name ends in .gz are gzip-compressed.\n";
 
 static void cmd_error(const string &msg) {
@@ -88,7 +89,7 @@ struct Options {
     unsigned excludes = EXCLUDE_NONE;
     string genome_fa;
     bool skip_missing_targets = false;
-    string junction_bed, intron_bed, intron_bed6, intron_call_tsv;
+    string junction_bed, intron_bed, intron_bed6, intron_call_tsv, debug_trace_tsv;
 };
 
 static void parse_options(int argc, char *argv[], Options &o) {
@@ -155,8 +156,9 @@ static void parse_options(int argc, char *argv[], Options &o) {
             case 'n': o.intron_bed = optarg; break;
             case 'b': o.intron_bed6 = optarg; break;
             case 'c': o.intron_call_tsv = optarg; break;
-            case 'p': case 'D': case OPT_XS: case OPT_TS:
-                cmd_error("--pass-through, --debug-trace and the strand-tag options are not part of the MI355X build");
+            case 'D': o.debug_trace_tsv = optarg; break;
+            case 'p': case OPT_XS: case OPT_TS:
+                cmd_error("--pass-through and the strand-tag options are not part of the MI355X build");
                 break;
             case 'h': cerr << usage_msg; exit(0);
             case 'v': cerr << "intronProspector 1.4.0 (MI355X junction-extraction build)" << endl; exit(0);
@@ -201,9 +203,12 @@ static void output_junctions(JunctionsExtractor &extractor, float min_confidence
 static void extract_junctions(const Options &o) {
     std::unique_ptr<Genome> genome;
     if (!o.genome_fa.empty()) genome.reset(new Genome(o.genome_fa));
+    // src/intronProspector.cc:408-415,427
+    std::unique_ptr<std::ostream> trace_fh;
+    if (!o.debug_trace_tsv.empty()) trace_fh.reset(new AutoGzipOutput(o.debug_trace_tsv));
     JunctionsExtractor extractor(o.min_anchor_length, o.max_anchor_indel_size, o.min_intron_length,
                                  o.max_intron_length, o.junction_filter, o.strandness, o.excludes, genome.get(),
-                                 o.skip_missing_targets);
+                                 o.skip_missing_targets, 0, &std::cerr, trace_fh.get());
     OutputFiles output(o);
     if (o.bam_files.size() > 1) {                       // :391-401
         for (const string &bam : o.bam_files) {

@@ -18,8 +18,9 @@ JunctionFilter junction_filter_parse(const std::string &spec) {
 JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_anchor_indel_size,
                                        uint32_t min_intron_length, uint32_t max_intron_length,
                                        JunctionFilter junction_filter, Strandness strandness, unsigned excludes,
-                                       Genome *genome, bool skip_missing_targets, int device, std::ostream *warn)
-    : genome_(genome), skip_missing_targets_(skip_missing_targets), warn_(warn) {
+                                       Genome *genome, bool skip_missing_targets, int device, std::ostream *warn,
+                                       std::ostream *trace_fh)
+    : genome_(genome), skip_missing_targets_(skip_missing_targets), warn_(warn), trace_fh_(trace_fh) {
     ipx_params p{};
     p.min_anchor_length = min_anchor_length;
     p.max_anchor_indel_size = max_anchor_indel_size;
@@ -86,6 +87,9 @@ void JunctionsExtractor::open(const std::string &bam) {
     for (size_t i = 0; i < targets_.size(); ++i) names[i] = targets_[i].c_str();
     int rc = ipx_set_targets(h_, (uint32_t)names.size(), names.data(), nullptr);
     if (rc != IPX_OK) throw_last_error(rc);
+    if (trace_fh_)          // junctions_extractor.cc:579-584 (nine names over ten columns, as there)
+        *trace_fh_ << "chrom" << "\t" << "intron_start" << "\t" << "intron_end" << "\t" << "qname" << "\t" << "flag" << "\t"
+                   << "strand" << "\t" << "splice_sites" << "\t" << "anchor_start" << "\t" << "anchor_end" << std::endl;
 }
 
 // junctions_extractor.cc:605-617
@@ -108,6 +112,10 @@ bool JunctionsExtractor::read_align() {
 void JunctionsExtractor::process_alignment(const AlnRecord &aln) {
     int32_t tid = aln.tid;
     if (tid >= 0 && (size_t)tid < canon_tid_.size()) tid = canon_tid_[tid];
+    if (trace_fh_) {
+        trace_qname_.push_back(aln.qname);
+        trace_flag_.push_back(aln.flag);
+    }
     b_tid_.push_back(tid);
     b_pos_.push_back((int32_t)aln.pos);
     b_flag_.push_back(aln.flag);
@@ -239,9 +247,52 @@ void JunctionsExtractor::finalize_table() {
     }
     // std::map<JunctionKey,...> order: chromosome NAME, start, end (junctions.hh:77-100).  Rows
     // arrive ordered by (first index of the name, start, end): a stable sort by name finishes it.
+    if (trace_fh_) write_trace(t);          // needs table_ in the device's row order
     std::stable_sort(table_.begin(), table_.end(),
                      [](const Junction &a, const Junction &b) { return a.chrom < b.chrom; });
     table_valid_ = true;
+}
+
+// --debug-trace: one line per record a junction counted, in input order.  create_junction
+// (junctions_extractor.cc:451-457) prints the junction's (corrected) strand and an empty column,
+// update_junction (:471-477) the read's strand and the junction's; both the junction's motif.
+// A table that is finalized again after more alignments only adds the lines of the new alignments.
+void JunctionsExtractor::write_trace(const ipx_table &t) {
+    uint64_t n = 0;
+    int rc = ipx_records_pending(h_, &n);
+    if (rc != IPX_OK) throw_last_error(rc);
+    std::vector<ipx_record> recs(n);
+    if (n) {
+        rc = ipx_records_export(h_, recs.data(), n, &n);
+        if (rc != IPX_OK) throw_last_error(rc);
+    }
+    std::sort(recs.begin(), recs.end(), [](const ipx_record &a, const ipx_record &b) { return a.order < b.order; });
+    for (const ipx_record &r : recs) {
+        const uint64_t read = IPX_RECORD_READ(r.order);
+        if (read < trace_done_) continue;
+        // the record's row: rows are ordered by (target, start, end)
+        uint64_t lo = 0, hi = t.n_junctions;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            const bool less = t.target[mid] != r.target ? t.target[mid] < r.target
+                              : t.intron_start[mid] != r.intron_start ? t.intron_start[mid] < r.intron_start
+                                                                       : t.intron_end[mid] < r.intron_end;
+            if (less) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= t.n_junctions || t.target[lo] != r.target || t.intron_start[lo] != r.intron_start ||
+            t.intron_end[lo] != r.intron_end)
+            continue;                                   // no record of this key passed the filter
+        const uint64_t seq = IPX_RECORD_SEQ(r.order);
+        if (seq < t.creator_order[lo]) continue;        // met before the junction was created: left no trace
+        const Junction &j = table_[lo];
+        const std::string &qname = trace_qname_[read - trace_base_];
+        const unsigned flag = trace_flag_[read - trace_base_];
+        *trace_fh_ << j.chrom << "\t" << r.intron_start << "\t" << r.intron_end << "\t" << qname << "\t" << flag << "\t";
+        if (seq == t.creator_order[lo]) *trace_fh_ << j.strand << "\t";
+        else *trace_fh_ << IPX_RECORD_STRAND(r.order) << "\t" << j.strand;
+        *trace_fh_ << "\t" << j.splice_sites << "\t" << r.anchor_start << "\t" << r.anchor_end << std::endl;
+    }
+    trace_done_ = next_read_index_;
 }
 
 // JunctionTable::get_junctions, junctions.hh:232-238
@@ -258,6 +309,9 @@ void JunctionsExtractor::clear() {
     table_valid_ = true;          // an empty table is the table of no records
     int rc = ipx_clear(h_);
     if (rc != IPX_OK) throw_last_error(rc);
+    trace_qname_.clear();
+    trace_flag_.clear();
+    trace_base_ = trace_done_ = next_read_index_;
 }
 
 }  // namespace ipxhost

@@ -9,8 +9,9 @@
 // sortedness check (junctions_extractor.cc:620-683), the target-name vector that
 // grows with every open() (:564-568), the running ijunc_ (:129,459-460), the
 // missing-sequence warnings (:411-416) and the translation of device error
-// reports into the reference's exceptions.  Pass-through and tag rewriting are not
-// part of the accelerated path and are not offered.
+// reports into the reference's exceptions, and the --debug-trace stream
+// (:451-457,471-477,579-584), rebuilt from the device's record list.  Pass-through and
+// tag rewriting are not offered.
 #ifndef IPX_HOST_JUNCTIONS_EXTRACTOR_HH
 #define IPX_HOST_JUNCTIONS_EXTRACTOR_HH
 #include <cstdint>
@@ -41,7 +42,7 @@ public:
     JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_anchor_indel_size, uint32_t min_intron_length,
                        uint32_t max_intron_length, JunctionFilter junction_filter, Strandness strandness,
                        unsigned excludes, Genome *genome, bool skip_missing_targets, int device = 0,
-                       std::ostream *warn = &std::cerr);
+                       std::ostream *warn = &std::cerr, std::ostream *trace_fh = nullptr);
     ~JunctionsExtractor();
     JunctionsExtractor(const JunctionsExtractor &) = delete;
     JunctionsExtractor &operator=(const JunctionsExtractor &) = delete;
@@ -80,6 +81,13 @@ private:
     // finalized table of the records pushed since the last clear()
     bool table_valid_ = false;
     JunctionVector table_;
+    // --debug-trace: names and flags of the alignments queued since the last clear()
+    std::ostream *trace_fh_;
+    uint64_t trace_base_ = 0;                 // read index of trace_qname_[0]
+    uint64_t trace_done_ = 0;                 // records with a smaller read index are already written
+    std::vector<std::string> trace_qname_;
+    std::vector<uint16_t> trace_flag_;
+    void write_trace(const ipx_table &t);
 
     bool read_align();
     void process_alignment(const AlnRecord &aln);

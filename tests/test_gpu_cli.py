@@ -25,7 +25,7 @@ def _run(cli, golden, name, outdir, inputs=None):
     gin = os.path.join(golden, "input")
     cmd = [cli] + [o.format(G=gin) for o in opts]
     outs = {"--junction-bed": "juncs.bed", "--intron-bed": "introns.bed", "--intron-calls": "introns.tsv"}
-    outs.update({k: v for k, v in extra.items() if k != "--debug-trace"})
+    outs.update(extra)
     for opt, suf in outs.items():
         cmd.append("%s=%s" % (opt, os.path.join(outdir, "%s.%s" % (name, suf))))
     cmd += inputs if inputs else [os.path.join(gin, i) for i in rule_inputs]
@@ -52,6 +52,24 @@ def test_cli_bam_input(cli, golden, tmp_path, name):
     bam = str(tmp_path / "test_basic.bam")
     bamio.sam_to_bam(os.path.join(golden, "input", "test_basic.sam"), bam)
     _run(cli, golden, name, str(tmp_path), inputs=[bam])
+
+
+def test_cli_debug_trace_multiple_inputs_and_filter(cli, oracle_cli, golden, tmp_path):
+    """--debug-trace beyond the reference's one golden trace: two inputs (one table, a header per
+    open), and a filter that drops early records (fail-then-pass), against the oracle's trace."""
+    gin = os.path.join(golden, "input")
+    cases = [(["--min-confidence-score=0.0", "--unsorted"], ["test_multi.one.sam", "test_multi.two.sam"]),
+             (["--min-confidence-score=0.0", "--genome-fasta=" + os.path.join(gin, "fake10_genome.fa"), "--sj-filter=canon"],
+              [os.path.join("..", "known", "fail_then_pass.sam")]),
+             (["--min-confidence-score=0.0", "--allow-anchor-indels"], ["ont.sam"])]
+    for k, (opts, inputs) in enumerate(cases):
+        paths = [os.path.join(gin, i) for i in inputs]
+        got, exp = str(tmp_path / ("got%d.tsv" % k)), str(tmp_path / ("exp%d.tsv" % k))
+        subprocess.run([cli] + opts + ["--debug-trace=" + got] + paths, check=True)
+        subprocess.run([oracle_cli] + opts + ["--debug-trace=" + exp] + paths, check=True)
+        with open(got, "rb") as f, open(exp, "rb") as g:
+            a, b = f.read(), g.read()
+        assert a == b and a.count(b"\n") > 1, "case %d" % k
 
 
 def test_cli_gzip_outputs(cli, golden, tmp_path):

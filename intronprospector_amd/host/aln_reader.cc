@@ -61,6 +61,8 @@ void AlnReader::parse_sam_header() {
     while (read_line()) {
         if (line_.empty()) continue;
         if (line_[0] != '@') { have_line_ = true; break; }
+        raw_header_ += line_;
+        raw_header_ += '\n';
         if (line_.compare(0, 4, "@SQ\t") == 0) {
             std::string sn;
             int64_t ln = -1;
@@ -97,6 +99,7 @@ bool AlnReader::read_sam(AlnRecord &rec) {
         p = e + 1;
     }
     if (nf < 11) throw std::runtime_error("Error reader BAM record: " + path_);
+    if (keep_raw_) rec.raw = line_;
     rec.qname.assign(f[0], flen[0]);
     rec.flag = (uint16_t)strtol(f[1], nullptr, 0);
     rec.tid = -1;
@@ -162,18 +165,24 @@ static uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16
 void AlnReader::parse_bam_header() {
     uint8_t w[4];
     read_exact(w, 4, "l_text");
+    raw_header_.append((const char *)w, 4);
     uint32_t l_text = le32(w);
     std::vector<char> text(l_text);
     if (l_text) read_exact(text.data(), l_text, "header text");
+    raw_header_.append(text.data(), l_text);
     read_exact(w, 4, "n_ref");
+    raw_header_.append((const char *)w, 4);
     uint32_t n_ref = le32(w);
     for (uint32_t i = 0; i < n_ref; ++i) {
         read_exact(w, 4, "l_name");
+        raw_header_.append((const char *)w, 4);
         uint32_t l_name = le32(w);
         std::string nm(l_name, '\0');
         read_exact(&nm[0], l_name, "ref name");
+        raw_header_.append(nm);
         if (!nm.empty() && nm.back() == '\0') nm.pop_back();
         read_exact(w, 4, "l_ref");
+        raw_header_.append((const char *)w, 4);
         names_.push_back(nm);
         lengths_.push_back((int32_t)le32(w));
     }
@@ -205,6 +214,10 @@ bool AlnReader::read_bam(AlnRecord &rec) {
     off += 4ull * n_cigar;
     off += (l_seq + 1) / 2 + l_seq;
     if (off > block) throw std::runtime_error("Error reader BAM record: " + path_);
+    if (keep_raw_) {
+        rec.raw.assign((const char *)b, block);
+        rec.aux_off = (uint32_t)off;
+    }
     // aux fields
     rec.xs = 0;
     rec.nh = 0;

@@ -26,6 +26,10 @@ struct AlnRecord {
     uint8_t nh = 0;        // 0 = no NH / <= 0, 1 = NH == 1, 2 = NH > 1
     std::vector<uint32_t> cigar;
     std::string qname;
+    // kept only when the reader was asked to (pass-through): the SAM line without its newline, or
+    // the BAM record without its block_size word; aux_off = offset of the BAM record's tag section
+    std::string raw;
+    uint32_t aux_off = 0;
 };
 
 class AlnReader {
@@ -38,6 +42,10 @@ public:
     const std::vector<std::string> &target_names() const { return names_; }
     const std::vector<int64_t> &target_lengths() const { return lengths_; }
     bool is_bam() const { return bam_; }
+    // pass-through needs the records and the header as they came
+    void keep_raw(bool on) { keep_raw_ = on; }
+    // SAM: the header lines; BAM: everything between the magic and the first record (l_text ... refs)
+    const std::string &raw_header() const { return raw_header_; }
     unsigned decode_threads() const { return bgzf_ ? bgzf_->threads() : 1; }
     // false at end of input; throws std::runtime_error on a malformed record
     bool read(AlnRecord &rec);
@@ -47,6 +55,8 @@ private:
     gzFile fh_ = nullptr;                    // SAM text, gzip'd SAM
     std::unique_ptr<BgzfReader> bgzf_;       // BAM: blocks inflated by a thread pool
     bool bam_ = false;
+    bool keep_raw_ = false;
+    std::string raw_header_;
     std::vector<std::string> names_;
     std::vector<int64_t> lengths_;
     // SAM text state

@@ -10,6 +10,9 @@
 //   ipx_host_check make-bam N OUT.bam
 //       N synthetic 100 bp spliced alignments (aM nN bM, sequence, qualities, NH/XS tags) as a BAM
 //       file, to time the decoder on
+//   ipx_host_check copy-aln IN OUT [XS|TS +|-]...
+//       pass-through writer: every record of IN to OUT in IN's container (SAM text / BAM), the given
+//       strand tags set on every record the way update_strand_tag does
 //   ipx_host_check bench-decode FILE [THREADS]
 //       decodes every record; prints records, seconds, records/s and compressed MB/s
 #include <chrono>
@@ -23,6 +26,7 @@
 #include "aln_reader.hh"
 #include "gz_ostream.hh"
 #include "junctions.hh"
+#include "pass_through.hh"
 
 using namespace ipxhost;
 
@@ -144,6 +148,26 @@ static int make_bam(uint64_t n, const char *path) {
     return 0;
 }
 
+static int copy_aln(int argc, char **argv) {
+    AlnReader rd(argv[2]);
+    PassThroughWriter out(argv[3], rd);
+    rd.keep_raw(true);
+    AlnRecord r;
+    while (rd.read(r)) {
+        if (argc == 4) { out.write(r, 0, false, false); continue; }
+        // one writer call per requested tag, so that "XS + TS -" can differ; the writer sets both from one count
+        bool xs = false, ts = false;
+        int orient = 0;
+        for (int i = 4; i + 1 < argc; i += 2) {
+            if (std::string(argv[i]) == "XS") xs = true; else ts = true;
+            orient = argv[i + 1][0] == '+' ? 1 : -1;
+        }
+        out.write(r, orient, xs, ts);
+    }
+    out.close();
+    return 0;
+}
+
 static int bench_decode(const char *path, const char *threads) {
     if (threads) setenv("IPX_DECODE_THREADS", threads, 1);
     const auto t0 = std::chrono::steady_clock::now();
@@ -168,6 +192,7 @@ int main(int argc, char **argv) {
     try {
         if (argc == 3 && std::string(argv[1]) == "dump-aln") return dump_aln(argv[2]);
         if (argc == 4 && std::string(argv[1]) == "print-table") return print_table(argv[2], strtof(argv[3], nullptr));
+        if (argc >= 4 && std::string(argv[1]) == "copy-aln") return copy_aln(argc, argv);
         if (argc == 4 && std::string(argv[1]) == "make-bam") return make_bam(strtoull(argv[2], nullptr, 10), argv[3]);
         if ((argc == 3 || argc == 4) && std::string(argv[1]) == "bench-decode") return bench_decode(argv[2], argc == 4 ? argv[3] : nullptr);
     } catch (const std::exception &e) {

@@ -3,8 +3,8 @@
 // option table :159-185, defaults :44-50, filter default :274-282, indel switch
 // :289-292, the three drivers :356-401, output_junctions :330-351, error exit :63-67.
 //
-// Not offered (outside the accelerated path): --pass-through,
-// --set-XS-strand-tag, --set-TS-strand-tag.
+// --pass-through, --set-XS/TS-strand-tag and --debug-trace are host work over the
+// device's record list (host/junctions_extractor.cc, host/pass_through.cc).
 #include <getopt.h>
 
 #include <algorithm>
@@ -43,7 +43,7 @@ static const char *usage_msg =
     "  -s, --strandness=UN|RF|FR   -X, --excludes=multi\n"
     "  -g, --genome-fasta=fasta (needs fasta.fai)   -f, --sj-filter=all|canon   -S, --skip-missing-targets\n"
     "  -j, --junction-bed=file   -n, --intron-bed=file   -b, --intron-bed6=file   -c, --intron-calls=file\n"
-    "  -D, --debug-trace=file\n"
+    "  -D, --debug-trace=file   -p, --pass-through=file   --set-XS-strand-tag   --set-TS-strand-tag\n"
     "Outputs whose name ends in .gz are gzip-compressed.\n";
 
 static void cmd_error(const string &msg) {
@@ -89,7 +89,8 @@ struct Options {
     unsigned excludes = EXCLUDE_NONE;
     string genome_fa;
     bool skip_missing_targets = false;
-    string junction_bed, intron_bed, intron_bed6, intron_call_tsv, debug_trace_tsv;
+    string junction_bed, intron_bed, intron_bed6, intron_call_tsv, debug_trace_tsv, bam_pass_through;
+    bool set_XS_strand_tag = false, set_TS_strand_tag = false;
 };
 
 static void parse_options(int argc, char *argv[], Options &o) {
@@ -157,9 +158,9 @@ static void parse_options(int argc, char *argv[], Options &o) {
             case 'b': o.intron_bed6 = optarg; break;
             case 'c': o.intron_call_tsv = optarg; break;
             case 'D': o.debug_trace_tsv = optarg; break;
-            case 'p': case OPT_XS: case OPT_TS:
-                cmd_error("--pass-through and the strand-tag options are not part of the MI355X build");
-                break;
+            case 'p': o.bam_pass_through = optarg; break;
+            case OPT_XS: o.set_XS_strand_tag = true; break;
+            case OPT_TS: o.set_TS_strand_tag = true; break;
             case 'h': cerr << usage_msg; exit(0);
             case 'v': cerr << "intronProspector 1.4.0 (MI355X junction-extraction build)" << endl; exit(0);
             case '?':
@@ -168,9 +169,13 @@ static void parse_options(int argc, char *argv[], Options &o) {
     }
     for (int i = optind; i < argc; ++i) o.bam_files.push_back(argv[i]);
     if (o.bam_files.empty()) o.bam_files.push_back("/dev/stdin");
+    if (o.bam_files.size() > 1 && !o.bam_pass_through.empty())                    // :269-271
+        cmd_error("can only have one input BAM with --bam-pass-through");
     if (o.junction_filter == CANON_SJ_FILTER && o.genome_fa.empty()) cmd_error("--sj-filter=canon requires --genome_fa");
     if (o.junction_filter == NULL_SJ_FILTER && !o.genome_fa.empty()) o.junction_filter = CANON_SJ_FILTER;
     if (!o.allow_anchor_indels) o.max_anchor_indel_size = 0;
+    if ((o.set_XS_strand_tag || o.set_TS_strand_tag) && (o.bam_pass_through.empty() || o.genome_fa.empty()))   // :294-298
+        cmd_error("--set-XS-strand-tag and --set-TS-strand-tag require --pass-through and --genome-fasta");
 }
 
 struct OutputFiles {
@@ -208,7 +213,8 @@ static void extract_junctions(const Options &o) {
     if (!o.debug_trace_tsv.empty()) trace_fh.reset(new AutoGzipOutput(o.debug_trace_tsv));
     JunctionsExtractor extractor(o.min_anchor_length, o.max_anchor_indel_size, o.min_intron_length,
                                  o.max_intron_length, o.junction_filter, o.strandness, o.excludes, genome.get(),
-                                 o.skip_missing_targets, 0, &std::cerr, trace_fh.get());
+                                 o.skip_missing_targets, 0, &std::cerr, trace_fh.get(), o.set_XS_strand_tag,
+                                 o.set_TS_strand_tag);
     OutputFiles output(o);
     if (o.bam_files.size() > 1) {                       // :391-401
         for (const string &bam : o.bam_files) {
@@ -219,16 +225,20 @@ static void extract_junctions(const Options &o) {
         output_junctions(extractor, o.min_confidence_score, output);
     } else if (o.unsorted) {                            // :375-387
         extractor.open(o.bam_files[0]);
+        if (!o.bam_pass_through.empty()) extractor.open_pass_through(o.bam_pass_through);
         extractor.identify_junctions_for_bam();
+        extractor.copy_unaligned_reads();
         extractor.close();
         output_junctions(extractor, o.min_confidence_score, output);
     } else {                                            // :356-371
         extractor.open(o.bam_files[0]);
+        if (!o.bam_pass_through.empty()) extractor.open_pass_through(o.bam_pass_through);
         for (int target_index = 0; target_index < extractor.get_num_targets(); target_index++) {
             extractor.identify_junctions_for_target(target_index);
             output_junctions(extractor, o.min_confidence_score, output);
             extractor.clear();
         }
+        extractor.copy_unaligned_reads();
         extractor.close();
     }
 }

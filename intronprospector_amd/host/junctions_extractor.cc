@@ -19,8 +19,9 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
                                        uint32_t min_intron_length, uint32_t max_intron_length,
                                        JunctionFilter junction_filter, Strandness strandness, unsigned excludes,
                                        Genome *genome, bool skip_missing_targets, int device, std::ostream *warn,
-                                       std::ostream *trace_fh)
-    : genome_(genome), skip_missing_targets_(skip_missing_targets), warn_(warn), trace_fh_(trace_fh) {
+                                       std::ostream *trace_fh, bool set_XS_strand_tag, bool set_TS_strand_tag)
+    : genome_(genome), skip_missing_targets_(skip_missing_targets), warn_(warn), trace_fh_(trace_fh),
+      set_xs_(set_XS_strand_tag), set_ts_(set_TS_strand_tag) {
     ipx_params p{};
     p.min_anchor_length = min_anchor_length;
     p.max_anchor_indel_size = max_anchor_indel_size;
@@ -92,8 +93,25 @@ void JunctionsExtractor::open(const std::string &bam) {
                    << "strand" << "\t" << "splice_sites" << "\t" << "anchor_start" << "\t" << "anchor_end" << std::endl;
 }
 
+// junctions_extractor.cc:589-602: same container as the input, header first
+void JunctionsExtractor::open_pass_through(const std::string &bam_pass_through) {
+    pass_through_.reset(new PassThroughWriter(bam_pass_through, *reader_));
+    reader_->keep_raw(true);
+}
+
+// junctions_extractor.cc:667-674: whatever the target loop left unread (unaligned reads, and
+// anything the sorted-mode loop never got to)
+void JunctionsExtractor::copy_unaligned_reads() {
+    if (!pass_through_) return;
+    while (read_align()) pass_through_->write(aln_buf_, 0, false, false);
+}
+
 // junctions_extractor.cc:605-617
 void JunctionsExtractor::close() {
+    if (pass_through_) {
+        pass_through_->close();
+        pass_through_.reset();
+    }
     reader_.reset();
     previous_target_ = -1;
     aln_pending_ = false;
@@ -159,6 +177,14 @@ void JunctionsExtractor::identify_junctions_for_target(int target_index) {
             break;
         }
         process_alignment(aln_buf_);
+        if (pass_through_) {                    // process_target_alignment, :647-650
+            if (set_xs_ || set_ts_) {
+                pt_pending_.push_back(aln_buf_);
+                pt_read_index_.push_back(next_read_index_ + b_tid_.size() - 1);
+            } else {
+                pass_through_->write(aln_buf_, 0, false, false);
+            }
+        }
     }
     previous_target_ = target_index;
     finalize_table();       // surfaces the reference's exceptions where its loop would throw
@@ -247,7 +273,11 @@ void JunctionsExtractor::finalize_table() {
     }
     // std::map<JunctionKey,...> order: chromosome NAME, start, end (junctions.hh:77-100).  Rows
     // arrive ordered by (first index of the name, start, end): a stable sort by name finishes it.
-    if (trace_fh_) write_trace(t);          // needs table_ in the device's row order
+    if (trace_fh_ || !pt_pending_.empty()) {     // both need table_ in the device's row order
+        const std::vector<ipx_record> recs = export_records();
+        if (trace_fh_) write_trace(t, recs);
+        if (!pt_pending_.empty()) write_pending_pass_through(t, recs);
+    }
     std::stable_sort(table_.begin(), table_.end(),
                      [](const Junction &a, const Junction &b) { return a.chrom < b.chrom; });
     table_valid_ = true;
@@ -257,7 +287,8 @@ void JunctionsExtractor::finalize_table() {
 // (junctions_extractor.cc:451-457) prints the junction's (corrected) strand and an empty column,
 // update_junction (:471-477) the read's strand and the junction's; both the junction's motif.
 // A table that is finalized again after more alignments only adds the lines of the new alignments.
-void JunctionsExtractor::write_trace(const ipx_table &t) {
+// the handle's records in the order the reference's loop met them
+std::vector<ipx_record> JunctionsExtractor::export_records() {
     uint64_t n = 0;
     int rc = ipx_records_pending(h_, &n);
     if (rc != IPX_OK) throw_last_error(rc);
@@ -267,23 +298,55 @@ void JunctionsExtractor::write_trace(const ipx_table &t) {
         if (rc != IPX_OK) throw_last_error(rc);
     }
     std::sort(recs.begin(), recs.end(), [](const ipx_record &a, const ipx_record &b) { return a.order < b.order; });
+    return recs;
+}
+
+// row of the junction that counted record r, or n_junctions: the key has no row (no record of it
+// passed the filter) or r came before the row's creator (left no trace)
+static uint64_t counting_row(const ipx_table &t, const ipx_record &r) {
+    uint64_t lo = 0, hi = t.n_junctions;               // rows are ordered by (target, start, end)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        const bool less = t.target[mid] != r.target ? t.target[mid] < r.target
+                          : t.intron_start[mid] != r.intron_start ? t.intron_start[mid] < r.intron_start
+                                                                   : t.intron_end[mid] < r.intron_end;
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= t.n_junctions || t.target[lo] != r.target || t.intron_start[lo] != r.intron_start ||
+        t.intron_end[lo] != r.intron_end || IPX_RECORD_SEQ(r.order) < t.creator_order[lo])
+        return t.n_junctions;
+    return lo;
+}
+
+// record_junction's orientCnt (junctions_extractor.cc:526-528) per waiting alignment, then
+// update_strand_tag + write_pass_through (:540-547,647-650)
+void JunctionsExtractor::write_pending_pass_through(const ipx_table &t, const std::vector<ipx_record> &recs) {
+    std::vector<int> orient(pt_pending_.size(), 0);
+    // read indices grow by one per processed alignment and every waiting alignment was processed,
+    // so the waiting ones hold consecutive indices
+    const uint64_t first = pt_read_index_.front();
+    for (const ipx_record &r : recs) {
+        const uint64_t read = IPX_RECORD_READ(r.order);
+        if (read < first || read - first >= orient.size()) continue;
+        const uint64_t row = counting_row(t, r);
+        if (row == t.n_junctions) continue;
+        const Junction &j = table_[row];
+        // Junction::is_canonical, junctions.hh:187-191: canonical sites are capitalized
+        if (!j.splice_sites.empty() && j.splice_sites[0] >= 'A' && j.splice_sites[0] <= 'Z')
+            orient[read - first] += (j.strand == '+') ? 1 : -1;
+    }
+    for (size_t i = 0; i < pt_pending_.size(); ++i) pass_through_->write(pt_pending_[i], orient[i], set_xs_, set_ts_);
+    pt_pending_.clear();
+    pt_read_index_.clear();
+}
+
+void JunctionsExtractor::write_trace(const ipx_table &t, const std::vector<ipx_record> &recs) {
     for (const ipx_record &r : recs) {
         const uint64_t read = IPX_RECORD_READ(r.order);
         if (read < trace_done_) continue;
-        // the record's row: rows are ordered by (target, start, end)
-        uint64_t lo = 0, hi = t.n_junctions;
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) / 2;
-            const bool less = t.target[mid] != r.target ? t.target[mid] < r.target
-                              : t.intron_start[mid] != r.intron_start ? t.intron_start[mid] < r.intron_start
-                                                                       : t.intron_end[mid] < r.intron_end;
-            if (less) lo = mid + 1; else hi = mid;
-        }
-        if (lo >= t.n_junctions || t.target[lo] != r.target || t.intron_start[lo] != r.intron_start ||
-            t.intron_end[lo] != r.intron_end)
-            continue;                                   // no record of this key passed the filter
+        const uint64_t lo = counting_row(t, r);
+        if (lo == t.n_junctions) continue;
         const uint64_t seq = IPX_RECORD_SEQ(r.order);
-        if (seq < t.creator_order[lo]) continue;        // met before the junction was created: left no trace
         const Junction &j = table_[lo];
         const std::string &qname = trace_qname_[read - trace_base_];
         const unsigned flag = trace_flag_[read - trace_base_];

@@ -10,8 +10,9 @@
 // grows with every open() (:564-568), the running ijunc_ (:129,459-460), the
 // missing-sequence warnings (:411-416) and the translation of device error
 // reports into the reference's exceptions, and the --debug-trace stream
-// (:451-457,471-477,579-584), rebuilt from the device's record list.  Pass-through and
-// tag rewriting are not offered.
+// (:451-457,471-477,579-584) and the per-read orientation count behind
+// --set-XS/TS-strand-tag (:526-528,540-547), both rebuilt from the device's record list,
+// and the pass-through output (:589-602,637-652,667-674; host/pass_through.hh).
 #ifndef IPX_HOST_JUNCTIONS_EXTRACTOR_HH
 #define IPX_HOST_JUNCTIONS_EXTRACTOR_HH
 #include <cstdint>
@@ -25,6 +26,7 @@
 #include "aln_reader.hh"
 #include "genome.hh"
 #include "junctions.hh"
+#include "pass_through.hh"
 
 namespace ipxhost {
 
@@ -42,12 +44,15 @@ public:
     JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_anchor_indel_size, uint32_t min_intron_length,
                        uint32_t max_intron_length, JunctionFilter junction_filter, Strandness strandness,
                        unsigned excludes, Genome *genome, bool skip_missing_targets, int device = 0,
-                       std::ostream *warn = &std::cerr, std::ostream *trace_fh = nullptr);
+                       std::ostream *warn = &std::cerr, std::ostream *trace_fh = nullptr,
+                       bool set_XS_strand_tag = false, bool set_TS_strand_tag = false);
     ~JunctionsExtractor();
     JunctionsExtractor(const JunctionsExtractor &) = delete;
     JunctionsExtractor &operator=(const JunctionsExtractor &) = delete;
 
     void open(const std::string &bam);
+    void open_pass_through(const std::string &bam_pass_through);
+    void copy_unaligned_reads();
     void close();
     int get_num_targets() const { return (int)targets_.size(); }
     void identify_junctions_for_target(int target_index);
@@ -87,7 +92,15 @@ private:
     uint64_t trace_done_ = 0;                 // records with a smaller read index are already written
     std::vector<std::string> trace_qname_;
     std::vector<uint16_t> trace_flag_;
-    void write_trace(const ipx_table &t);
+    void write_trace(const ipx_table &t, const std::vector<ipx_record> &recs);
+    // --pass-through: alignments of the current target wait here for their orientation count when a
+    // strand tag is to be set (the count needs the target's table); otherwise they are written at once
+    bool set_xs_, set_ts_;
+    std::unique_ptr<PassThroughWriter> pass_through_;
+    std::vector<AlnRecord> pt_pending_;
+    std::vector<uint64_t> pt_read_index_;
+    void write_pending_pass_through(const ipx_table &t, const std::vector<ipx_record> &recs);
+    std::vector<ipx_record> export_records();
 
     bool read_align();
     void process_alignment(const AlnRecord &aln);

@@ -72,6 +72,43 @@ def test_cli_debug_trace_multiple_inputs_and_filter(cli, oracle_cli, golden, tmp
         assert a == b and a.count(b"\n") > 1, "case %d" % k
 
 
+def test_cli_pass_through_and_strand_tags(cli, golden, tmp_path):
+    """tests/Makefile.in:120-123,133-136 diff the pass-through against the input; the reference also
+    keeps two outputs of the strand-tag options (expected/testStrandTag{Add,Update}.sam, no rule)."""
+    gin, gexp = os.path.join(golden, "input"), os.path.join(golden, "expected")
+    fa = "--genome-fasta=" + os.path.join(gin, "fake10_genome.fa")
+    star, hisat = os.path.join(gin, "fake10.star.sam"), os.path.join(gin, "fake10.hisat2.sam")
+    out = str(tmp_path / "pt.sam")
+    calls = "--intron-calls=" + str(tmp_path / "calls.tsv")
+    subprocess.run([cli, "--min-confidence-score=0.0", fa, calls, "--pass-through=" + out, star], check=True)
+    assert open(out, "rb").read() == open(star, "rb").read()
+    with open(os.path.join(gexp, "testFake10a.introns.tsv"), "rb") as f:
+        assert open(str(tmp_path / "calls.tsv"), "rb").read() == f.read()
+    subprocess.run([cli, fa, "--set-XS-strand-tag", "--set-TS-strand-tag", "--pass-through=" + out, star], check=True)
+    assert open(out, "rb").read() == open(os.path.join(gexp, "testStrandTagAdd.sam"), "rb").read()
+    subprocess.run([cli, fa, "--set-XS-strand-tag", "--pass-through=" + out, hisat], check=True)
+    assert open(out, "rb").read() == open(os.path.join(gexp, "testStrandTagUpdate.sam"), "rb").read()
+    # BAM in, BAM out; same tags as the SAM run
+    bam, bam_out = str(tmp_path / "star.bam"), str(tmp_path / "pt.bam")
+    bamio.sam_to_bam(star, bam)
+    subprocess.run([cli, fa, "--set-XS-strand-tag", "--pass-through=" + bam_out, bam], check=True)
+    hc = os.path.join(os.path.dirname(cli), "ipx_host_check")
+    got = subprocess.run([hc, "dump-aln", bam_out], stdout=subprocess.PIPE, check=True).stdout
+    sam_out = str(tmp_path / "pt2.sam")
+    subprocess.run([cli, fa, "--set-XS-strand-tag", "--pass-through=" + sam_out, star], check=True)
+    exp = subprocess.run([hc, "dump-aln", sam_out], stdout=subprocess.PIPE, check=True).stdout
+    assert got == exp and b"\t43\t" in got
+    # the reference's --unsorted loop never writes the alignments (identify_junctions_for_bam,
+    # junctions_extractor.cc:678-683): header only
+    subprocess.run([cli, "--unsorted", fa, "--pass-through=" + out, star], check=True)
+    assert open(out).read() == "".join(l for l in open(star) if l.startswith("@"))
+    # option checks, src/intronProspector.cc:269-271,294-298
+    r = subprocess.run([cli, "--set-XS-strand-tag", star], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"require --pass-through and --genome-fasta" in r.stderr
+    r = subprocess.run([cli, "--pass-through=" + out, star, hisat], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"can only have one input BAM" in r.stderr
+
+
 def test_cli_gzip_outputs(cli, golden, tmp_path):
     import gzip
     out = {s: str(tmp_path / ("b1." + s + ".gz")) for s in ("juncs.bed", "introns.bed", "introns.tsv")}

@@ -126,6 +126,45 @@ def test_bgzf_blocks_inflate_in_parallel_in_file_order(host_check, tmp_path):
     assert r.returncode == 1 and b"Error reader BAM record" in r.stderr
 
 
+def test_pass_through_writer_and_strand_tag_edits(host_check, golden, tmp_path):
+    """host/pass_through.cc (SURVEY 8f-2): SAM and BAM pass-through keep every record as it came;
+    update_strand_tag semantics (src/junctions_extractor.cc:98-111): the first tag of that name goes,
+    the new one (type A) is appended."""
+    src = os.path.join(golden, "input", "fake10.hisat2.sam")          # carries XS:A tags in the middle
+    out = str(tmp_path / "copy.sam")
+    subprocess.run([host_check, "copy-aln", src, out], check=True)
+    assert open(out, "rb").read() == open(src, "rb").read()
+    subprocess.run([host_check, "copy-aln", src, out, "XS", "-", "TS", "-"], check=True)
+    exp = []
+    for line in open(src):
+        line = line.rstrip("\n")
+        if not line.startswith("@"):
+            f = line.split("\t")
+            tags = f[11:]
+            for k, t in enumerate(tags):
+                if t.startswith("XS:"):
+                    del tags[k]
+                    break
+            line = "\t".join(f[:11] + tags + ["XS:A:-", "TS:A:-"])
+        exp.append(line + "\n")
+    assert open(out).read() == "".join(exp)
+    # BAM: same records after the round trip; tags readable by the decoder; CG-tag CIGARs survive
+    bam, bam2, bam3 = (str(tmp_path / n) for n in ("in.bam", "copy.bam", "tag.bam"))
+    bamio.sam_to_bam(src, bam)
+    subprocess.run([host_check, "copy-aln", bam, bam2], check=True)
+    assert _dump(host_check, bam2) == _dump(host_check, bam) == _dump(host_check, src)
+    subprocess.run([host_check, "copy-aln", bam, bam3, "XS", "+"], check=True)
+    names, rows = _dump(host_check, bam3)
+    ref_names, ref_rows = _dump(host_check, bam)
+    assert names == ref_names and len(rows) == len(ref_rows)
+    assert all(r[3] == ord("+") for r in rows)
+    assert [r[:3] + r[4:] for r in rows] == [r[:3] + r[4:] for r in ref_rows]
+    # the copied BAM is a well-formed BGZF file to an independent reader
+    import gzip
+    assert gzip.open(bam2, "rb").read() == gzip.open(bam, "rb").read()
+    assert open(bam2, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
 def _table_text(t, names):
     """oracle table (std::map order) -> the text form ipx_host_check print-table reads."""
     lines = []

@@ -28,6 +28,8 @@ def make_workload(kind, reads, seed):
     from intronprospector_amd import synth
     if kind == "S":
         return synth.short_reads(reads, seed=seed)
+    if kind == "G":     # S with a synthetic genome: strand / motif inference, --sj-filter=canon
+        return synth.short_reads(reads, seed=seed, genome=True)
     if kind == "L":
         return synth.long_reads(reads, seed=seed)
     raise SystemExit("unknown workload %r" % kind)
@@ -70,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="S", choices=["S", "L"])
+    ap.add_argument("--workload", default="S", choices=["S", "L", "G"])
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10M for S, 200k for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,10 +106,10 @@ def main():
     from intronprospector_amd import _lib as L
 
     kind = args.workload
-    reads = args.reads or (10_000_000 if kind == "S" else 200_000)
-    seed = (synth.SEED_S if kind == "S" else synth.SEED_L) if world == 1 else synth.SEED_M0 + rank
+    reads = args.reads or (200_000 if kind == "L" else 10_000_000)
+    seed = (synth.SEED_L if kind == "L" else synth.SEED_S) if world == 1 else synth.SEED_M0 + rank
     t_gen = time.perf_counter()
-    batch, names, _ = make_workload(kind, reads, seed)
+    batch, names, genome = make_workload(kind, reads, seed)
     t_gen = time.perf_counter() - t_gen
     n = len(batch["tid"])
     n_words = len(batch["cigar"])
@@ -118,6 +120,10 @@ def main():
     torch.cuda.synchronize()
 
     params = {"max_anchor_indel_size": 36} if kind == "L" else {}
+    if genome is not None:      # device 2-bit genome; filter as the command line defaults to with a genome
+        params["genome"] = (genome.names, [(t, m, len(q)) for (t, m), q in zip(genome.twobit(), genome.seqs)])
+        params["junction_filter"] = L.IPX_SJ_CANON
+        genome = None
     ex = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
     ex.reserve(0, 0, n_words // 2 + 1024)
 
@@ -217,14 +223,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d synthetic %s per GPU, %.2f CIGAR ops and %.2f junction records per "
                                    "alignment, %d junctions in the table" %
-                                   (kind, n, "100 bp short reads (1-2 N ops)" if kind == "S" else "ONT-style long reads",
+                                   (kind, n, "ONT-style long reads" if kind == "L" else "100 bp short reads (1-2 N ops)" +
+                                    (", device 2-bit genome, --sj-filter=canon" if kind == "G" else ""),
                                     c, j, n_junctions),
                        "alignments_per_gpu": n, "cigar_words": n_words, "records": r, "junctions": n_junctions,
                        "seed": seed, "generate_s": t_gen},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or (4_000_000 if kind == "S" else 20_000)
+            sample = args.cpu_sample or (20_000 if kind == "L" else 4_000_000)
             out["cpu_baseline"] = cpu_baseline(batch, names, kind, sample)
         print(json.dumps(out))
     ex.close()

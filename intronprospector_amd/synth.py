@@ -179,7 +179,7 @@ def short_reads(n, seed=SEED_S, n_targets=8, target_len=125_000_000, n_sites=200
     indel_is_del = rng.random(n) < 0.5
     indel_len = rng.integers(1, 4, n)
     a1 = np.where(indel, rng.integers(1, 10 ** 9, n) % np.maximum(a - 1, 1) + 1, a)
-    a1 = np.minimum(a1, np.maximum(a - 1, 1))
+    a1 = np.where(indel, np.minimum(a1, np.maximum(a - 1, 1)), a)      # without an indel the anchor is one M op
     a2 = a - a1
     u = rng.random(n)
     eqx = u < 0.01

@@ -80,6 +80,8 @@ def main():
                     help="N>1: exchange junction records by key range (default) or merge shard tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a one-GPU box (tables merged on the CPU)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="N=1 only: run the N>1 code path (process group of one rank) to exercise the RCCL calls")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,8 +96,10 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_collectives
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
         else:
@@ -129,7 +133,7 @@ def main():
 
     merger = None
     exchanger = None
-    if world > 1:
+    if multi:
         from intronprospector_amd import distributed
         comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
         if args.multi == "tables":
@@ -147,9 +151,7 @@ def main():
             # junction records -> key-range owners over RCCL (all_to_all), then the local finalize
             table, ijunc = exchanger.run(ex, n)
             n_records[0] = table.n_records
-            tot = torch.tensor([int(table.n_junctions)], dtype=torch.int64, device=comm_dev)
-            dist.all_reduce(tot)
-            n_merged[0] = int(tot.item())
+            n_merged[0] = int(table.n_junctions)          # this rank's key range; summed after the timed loop
             return table
         if merger is not None:
             # partial tables of this rank's shard -> RCCL merge of the junction tables
@@ -166,23 +168,27 @@ def main():
     for _ in range(args.warmup):
         table = step()
     ex.profile(True)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         table = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stats = ex.profile_read()
     ex.profile(False)
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    n_junctions = n_merged[0] if world > 1 else int(table.n_junctions)
+    if exchanger is not None:
+        tot = torch.tensor([n_merged[0]], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(tot)
+        n_merged[0] = int(tot.item())
+    n_junctions = n_merged[0] if multi else int(table.n_junctions)
     r = int(n_records[0])
 
     if rank == 0:
@@ -235,7 +241,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, names, kind, sample)
         print(json.dumps(out))
     ex.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -468,10 +468,21 @@ struct LongStage {                            // next 64 alignments of a wave, o
 
 struct __attribute__((packed, aligned(4))) Words4 { uint32_t x, y, z, w; };
 
-// copy of the last 8 CIGAR words followed by 8 zero words (see ipx_launch_scan)
+// copy of the last (up to) 8 CIGAR words followed by zero words (see ipx_launch_scan): a 16-byte load
+// that would reach past the end of the array reads here instead
 __global__ void k_cigar_tail(const uint32_t *__restrict__ cigar, uint64_t n_words, uint32_t *__restrict__ tail) {
     const uint32_t t = threadIdx.x;
-    if (t < 16) tail[t] = (t < 8 && n_words >= 8) ? cigar[n_words - 8 + t] : 0u;
+    const uint64_t tb = n_words >= 8 ? n_words - 8 : 0;
+    if (t < 16) tail[t] = (tb + t < n_words) ? cigar[tb + t] : 0u;
+}
+
+// four words starting at word w of the CIGAR array (w < n_words); only the address is selected
+__device__ __forceinline__ uint4 load_cigar4(const uint32_t *__restrict__ cigar, const uint32_t *__restrict__ tail,
+                                             uint64_t n_words, uint64_t w) {
+    const uint64_t tb = n_words >= 8 ? n_words - 8 : 0;
+    const uint32_t *ptr = (w + 4 <= n_words) ? cigar + w : tail + (w - tb);
+    const Words4 v = *reinterpret_cast<const Words4 *>(ptr);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
@@ -498,12 +509,7 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
     KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
     unsigned long long my_err = IPX_ERRW_NONE;
 
-    // four words starting at word w of the CIGAR array (w < n_words); only the address is selected
-    auto load4 = [&](uint64_t w) {
-        const uint32_t *ptr = (w + 4 <= n_words) ? cigar + w : tail + (w - (n_words - 8));
-        const Words4 v = *reinterpret_cast<const Words4 *>(ptr);
-        return make_uint4(v.x, v.y, v.z, v.w);
-    };
+    auto load4 = [&](uint64_t w) { return load_cigar4(cigar, tail, n_words, w); };
 
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
     uint64_t next = gw * reads_per_wave;          // wave-uniform from here on
@@ -792,6 +798,295 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
     }
 }
 
+// ---- short CIGARs, second generation ------------------------------------------------------------
+// k_scan_short: k_scan's tile structure (one lane per alignment, RPT alignments per thread, records
+// staged in an LDS pool, ONE global atomic per tile) around the select-based walk of k_scan_long.  A
+// CIGAR of up to 8 ops arrives as two 16-byte loads instead of one dependent 4-byte load per op; the
+// eight ops run unrolled (the wave leaves when all its lanes are done); 8 ops of < 2^28 cannot carry
+// out of 32-bit offsets.  A finished junction is snapshotted; snapshots are QC'd, packed and stored for
+// all lanes of the wave at once -- when a lane is about to finish a second junction, and at the end.
+// Alignments with more than 8 ops in such a batch (a few per cent at most) take run_read<2>.
+template <uint32_t RPT, uint32_t POOL>
+__global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
+                                                    const int32_t *__restrict__ a_tid,
+                                                    const int32_t *__restrict__ a_pos,
+                                                    const uint16_t *__restrict__ a_flag,
+                                                    const uint8_t *__restrict__ a_xs,
+                                                    const uint8_t *__restrict__ a_nh,
+                                                    const uint32_t *__restrict__ a_off,
+                                                    const uint32_t *__restrict__ a_nc,
+                                                    const uint32_t *__restrict__ cigar,
+                                                    const uint32_t *__restrict__ tail,
+                                                    const uint32_t *__restrict__ rank_of_tid,
+                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                                    uint8_t *__restrict__ digs,
+                                                    uint64_t capacity, Counters *counters) {
+    __shared__ uint32_t wsum[RPT][4];
+    __shared__ uint32_t kb_s[4][6];
+    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
+    __shared__ uint32_t cnt_s[RPT][256], base_s[RPT][256];
+    __shared__ unsigned long long tile_slot;
+    __shared__ uint4 pool_item[POOL], pool_pay[POOL];
+    __shared__ uint32_t pool_n;
+    const Pool pool{pool_item, pool_pay, &pool_n, POOL};
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t n_tiles = (n + 256ull * RPT - 1) / (256ull * RPT);
+
+    auto load_ctx = [&](uint64_t i, ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
+        c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = base_read_index + i;
+        nc = 0; off = 0;
+        if (i < n) {
+            const int32_t tid = a_tid[i];
+            c.flag = a_flag[i];
+            nc = a_nc[i];
+            // junctions_extractor.cc:536
+            if (nc <= 1 || tid < 0 || (c.flag & (F_QCFAIL | F_DUP))) nc = 0;
+            if (nc) {
+                if ((uint32_t)tid >= p.n_targets) {
+                    const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
+                    err = e < err ? e : err;
+                    nc = 0;
+                } else {
+                    c.pos = a_pos[i];
+                    off = a_off[i];
+                    if ((uint64_t)off + nc > n_words) {          // words outside the batch: never dereferenced
+                        const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
+                        err = e < err ? e : err;
+                        nc = 0;
+                    }
+                    c.nhc = a_nh[i];
+                    c.rank = rank_of_tid[tid];
+                    const uint32_t xs = a_xs[i];
+                    c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
+                                                                : (xs ? xs : (uint32_t)'.');
+                }
+            }
+        }
+        c.cat = read_category(c.flag, c.nhc);
+        c.read_rejected = (c.flag & F_SECONDARY) || (p.exclude_multi && c.nhc == 2);
+    };
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        unsigned long long my_err = IPX_ERRW_NONE;
+        if (t == 0) pool_n = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t r = 0; r < RPT; ++r) {
+            const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+            ReadCtx c;
+            uint32_t nc, off;
+            load_ctx(i, c, nc, off, my_err);
+            const bool small = nc != 0 && nc <= 8;
+            // both chunks always (a lane without a short CIGAR reads the array's first words)
+            const uint4 wa = load_cigar4(cigar, tail, n_words, small ? (uint64_t)off : 0ull);
+            const uint4 wb = load_cigar4(cigar, tail, n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
+            const uint32_t pos32 = (uint32_t)c.pos;
+
+            bool active = small, pending = false, fin = false;
+            uint32_t left = small ? nc : 0u;
+            uint32_t state = ST_LIMBO;
+            uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;
+            uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
+            uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;
+
+            auto snap_ok = [&]() {
+                const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
+                const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
+                const uint32_t ilen = q_ie - q_is;
+                return !c.read_rejected && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
+                       (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
+                       (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
+            };
+            // QC, pack and store the waiting snapshots of the whole wave
+            auto drain = [&]() {
+                const bool pass = pending && snap_ok();
+                const unsigned long long em = __ballot(pass);
+                if (em) {
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)(__ffsll((unsigned long long)em) - 1)) base = atomicAdd(&pool_n, (uint32_t)__popcll(em));
+                    base = __shfl(base, __ffsll((unsigned long long)em) - 1);
+                    if (pass) {
+                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
+                                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                        if (slot < POOL) {
+                            ReadCtx cc = c;
+                            cc.pos = 0;
+                            uint4 it, pay;
+                            const Rec rr{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
+                                         (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
+                            pack_record_rel(p, cc, rr, pos32, ordinal, it, pay);
+                            pool_item[slot] = it;
+                            pool_pay[slot] = pay;
+                        }
+                        ++ordinal;
+                    }
+                }
+                pending = false;
+                fin = false;
+            };
+            auto step = [&](uint32_t w) {
+                const bool run = active && left != 0;
+                const uint32_t op = w & 0xfu, len = w >> 4;
+                const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
+                const bool c_m = run && (cls & 1u), c_n = run && (cls & 2u), c_id = run && (cls & 4u), c_sh = run && (cls & 8u);
+                const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
+                lind += (c_id && in_l) ? len : 0u;
+                rind += (c_id && in_r) ? len : 0u;
+                const uint32_t indel2 = cur_indel + len;
+                const bool over = c_id && indel2 > p.max_anchor_indel_size;
+                const bool trig = in_r && (c_n || c_sh || over);
+                const bool last = run && left == 1;
+                if (__ballot(pending && (trig || last))) drain();
+                s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
+                s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
+                pending = pending || trig;
+                const uint32_t tpn = tp + len;
+                const bool adv = c_m || c_n || (c_id && op == 2);
+                const bool bad = run && cls == 0;
+                if (__ballot(bad)) {
+                    if (bad) {                                              // :312-313: the exception ends the read
+                        const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
+                        const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
+                        const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) |
+                                                     ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
+                                                     (IPX_ERRK_CIGAR << 8) | ch;
+                        my_err = e < my_err ? e : my_err;
+                    }
+                }
+                const bool n_r = c_n && in_r, n_lr = c_n && (in_l || in_r);
+                const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
+                const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
+                const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
+                is = n_lr ? tp : is;
+                as = as2;
+                ie = ie2;
+                ae = c_m ? tpn : ae;
+                uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);
+                uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;
+                lind = n_r ? rind : lind;
+                rind = n_r ? 0u : rind;
+                state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
+                const bool x = c_m && op == 8;
+                lmm2 += (x && state == ST_LEFT) ? len : 0u;
+                rmm2 += (x && state == ST_RIGHT) ? len : 0u;
+                lmm = lmm2;
+                rmm = rmm2;
+                cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
+                tp = adv ? tpn : tp;
+                fin = fin || (last && !bad && state == ST_RIGHT);   // finish(): never together with `trig`; kept until the drain
+                pending = pending || fin;
+                left -= run ? 1u : 0u;
+                active = run && !last && !bad;
+            };
+            step(wa.x);
+            step(wa.y);
+            if (__ballot(active)) step(wa.z);
+            if (__ballot(active)) step(wa.w);
+            if (__ballot(active)) step(wb.x);
+            if (__ballot(active)) step(wb.y);
+            if (__ballot(active)) step(wb.z);
+            if (__ballot(active)) step(wb.w);
+            if (__ballot(pending)) drain();
+            // CIGARs of more than 8 ops in a short-CIGAR batch: the op-by-op walk
+            if (__ballot(nc > 8)) {
+                if (nc > 8) (void)run_read<2>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err, &pool);
+            }
+        }
+        __syncthreads();
+        const uint32_t total = pool_n;
+        if (total <= POOL) {
+            if (t == 0) tile_slot = total ? atomicAdd(&counters->n_records, (unsigned long long)total) : 0ull;
+            __syncthreads();
+            const uint64_t slot = tile_slot;
+            for (uint32_t k = t; k < total; k += 256) {
+                const uint64_t idx = slot + k;
+                if (idx < capacity) {
+                    uint4 it = pool_item[k];
+                    it.w = (uint32_t)idx;
+                    items[idx] = it;
+                    pays[idx] = pool_pay[k];
+                    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+                }
+            }
+        } else {
+            // the pool overflowed: count, reserve, re-run (k_scan's scheme); errors were collected above
+#pragma unroll 1
+            for (uint32_t r = 0; r < RPT; ++r) {
+                const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+                unsigned long long dummy = IPX_ERRW_NONE;
+                ReadCtx c;
+                uint32_t nc, off;
+                load_ctx(i, c, nc, off, dummy);
+                const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, dummy) : 0;
+                cnt_s[r][t] = cn;
+                uint32_t v = cn;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t x = __shfl_up(v, o);
+                    if ((int)lane >= o) v += x;
+                }
+                base_s[r][t] = v - cn;
+                if (lane == 63) wsum[r][wave] = v;
+            }
+            __syncthreads();
+            uint32_t tile_total = 0;
+#pragma unroll 1
+            for (uint32_t r = 0; r < RPT; ++r) {
+                uint32_t before = tile_total;
+                for (uint32_t w = 0; w < 4; ++w) {
+                    const uint32_t sw = wsum[r][w];
+                    if (w < wave) before += sw;
+                    tile_total += sw;
+                }
+                base_s[r][t] += before;
+            }
+            if (t == 0) tile_slot = tile_total ? atomicAdd(&counters->n_records, (unsigned long long)tile_total) : 0ull;
+            __syncthreads();
+            const uint64_t slot = tile_slot;
+#pragma unroll 1
+            for (uint32_t r = 0; r < RPT; ++r) {
+                if (cnt_s[r][t]) {
+                    const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+                    unsigned long long dummy = IPX_ERRW_NONE;
+                    ReadCtx c;
+                    uint32_t nc, off;
+                    load_ctx(i, c, nc, off, dummy);
+                    (void)run_read<1>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy);
+                }
+            }
+        }
+        unsigned long long e = my_err;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(e, d);
+            e = o < e ? o : e;
+        }
+        if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+        __syncthreads();
+    }
+    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const uint32_t o = __shfl_xor(v[k], dlt);
+            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
+        }
+        if (lane == 0) kb_s[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (t < 6) {
+        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        if (t < 3) {
+            const uint32_t o = x0 | x1 | x2 | x3;
+            if (o) atomicOr(&counters->key_or[t], o);
+        } else {
+            const uint32_t a = x0 & x1 & x2 & x3;
+            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
@@ -803,10 +1098,18 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
     const uint64_t per_tile = short_reads ? 512 : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
     if (blocks > 256ull * 16) blocks = 256ull * 16;
-    if (short_reads)
+    // the Counters allocation is 256 bytes; bytes 128..191 hold the copy of the array's last words
+    uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + 128);
+    hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
+    static const bool old_short = [] { const char *e = getenv("IPX_SCAN_SHORT"); return e && e[0] == 'o'; }();
+    if (short_reads && old_short)
         hipLaunchKernelGGL((k_scan<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
+    else if (short_reads)
+        hipLaunchKernelGGL((k_scan_short<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
+                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
     else {
         // long CIGARs: waves work through ranges of >= 64 alignments
         static const uint32_t min_range = [] {
@@ -820,9 +1123,6 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
         // few alignments per lane: whole multiples of 64, or one lane's second alignment doubles the wave's time
         if (per_wave < 256) per_wave = (per_wave + 63) / 64 * 64;
         const uint64_t waves = ipx_div_up(b.n_alignments, per_wave);
-        // the Counters allocation is 256 bytes; bytes 128..191 hold the copy of the array's last words
-        uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + 128);
-        hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
         hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                            b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);

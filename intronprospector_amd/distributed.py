@@ -31,7 +31,7 @@ def _all_gather_var(t, group=None):
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = torch.cat(sizes).cpu().tolist()          # one read-back
     m = max(max(sizes), 1)
     pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
@@ -225,7 +225,7 @@ class RecordExchanger:
         c = torch.from_numpy(counts.astype(np.int64)).to(self.comm_device)
         cm = [torch.empty_like(c) for _ in range(world)]
         dist.all_gather(cm, c, group=self.group)
-        recv_counts = [int(x[rank].item()) for x in cm]
+        recv_counts = torch.stack(cm)[:, rank].cpu().tolist()          # one read-back, not one per rank
         n_recv = sum(recv_counts)
         send_c = self._to_comm(send[:n_local * 32])
         recv_c = torch.empty(max(n_recv, 1) * 32, dtype=torch.uint8, device=self.comm_device)

@@ -110,7 +110,7 @@ struct ipx_handle {
     // holds records; an empty handle takes `first_hint`: the window the last sort would have liked
     // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
     DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
-    DevBuf counters, stage, sort_ws, pass_skip, scratch, out_arena, rank_skip, d_small, out_arena2, d_xchg;
+    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
     void *pin_out = nullptr, *pin_out2 = nullptr;
@@ -317,8 +317,6 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
     if (hipHostMalloc(&h->pin_small, 4096, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
     int rc = ensure(h, h->counters, 256);      // Counters + ipx_scan.hip's copy of the CIGAR tail at byte 128
-    if (!rc) rc = ensure(h, h->pass_skip, 16 * sizeof(uint32_t));
-    if (!rc) rc = ensure(h, h->rank_skip, 16 * sizeof(uint32_t));
     if (!rc) rc = ensure(h, h->d_small, 64 * sizeof(uint32_t));
     if (!rc) rc = reset_counters(h);
     if (!rc) rc = rebuild_ranks(h);
@@ -333,8 +331,8 @@ int ipx_destroy(ipx_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->dig_a, &h->dig_b,
-                      &h->counters, &h->stage, &h->sort_ws, &h->pass_skip, &h->scratch, &h->out_arena,
-                      &h->rank_skip, &h->d_small, &h->out_arena2, &h->d_xchg})
+                      &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
+                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -666,10 +664,31 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         if (n_valid) {
             // creation-order keys: only the bits on which they differ (OR ^ AND, small[3..6]) need passes
             const uint32_t rvary[3] = {small[3] ^ small[5], small[4] ^ small[6], 0u};
-            const SortPlan rp = ipx_plan_sort(rvary, 64, nullptr);
-            HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
-                                   ipx_sort_workspace_bytes(J), IPXK_RANK_SORT));
-            HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));
+            // few varying bits in few runs: rank through a bitmap (5 small launches); else a radix sort
+            RankBits rbits{};
+            const uint64_t rv = (uint64_t)rvary[0] | ((uint64_t)rvary[1] << 32);
+            bool by_bitmap = true;
+            for (uint32_t b = 0; b < 64;) {
+                if (!((rv >> b) & 1u)) { ++b; continue; }
+                uint32_t w = 0;
+                while (b + w < 64 && ((rv >> (b + w)) & 1u)) ++w;
+                if (rbits.n_runs == 4) { by_bitmap = false; break; }
+                rbits.lo[rbits.n_runs] = b;
+                rbits.width[rbits.n_runs++] = w;
+                rbits.bits += w;
+                b += w;
+            }
+            const char *rank_env = getenv("IPX_RANK");                  // "sort": always the radix sort (tests)
+            const bool force_sort = rank_env && rank_env[0] == 's';
+            if (by_bitmap && rbits.bits <= 28 && !force_sort) {
+                if ((rc = ensure(h, h->rank_bitmap, ipx_rank_bitmap_workspace_bytes(rbits.bits)))) return rc;
+                HIPCHK(ipx_launch_rank_by_bitmap(s, n_valid, rb.rank_a, rbits, h->rank_bitmap.as<uint32_t>(), rb.out_ijunc));
+            } else {
+                const SortPlan rp = ipx_plan_sort(rvary, 64, nullptr);
+                HIPCHK(ipx_launch_sort(s, rb.rank_a, rb.rank_b, nullptr, nullptr, false, n_valid, rp, rank_ws,
+                                       ipx_sort_workspace_bytes(J), IPXK_RANK_SORT));
+                HIPCHK(ipx_launch_emit_ijunc(s, n_valid, (rp.n & 1u) ? rb.rank_b : rb.rank_a, rb.out_ijunc));
+            }
         }
         if (err_word != IPX_ERRW_NONE && ((err_word >> 8) & 3u) == IPX_ERRK_GENOME) {
             HIPCHK(hipMemsetAsync(detail4, 0, 16, s));

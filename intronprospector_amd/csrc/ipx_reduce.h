@@ -36,6 +36,18 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                              const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters);
 hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *sorted_rank_items, uint32_t *ijunc);
+
+// ijunc without a sort: the creation-order keys (rank_items[o].x/.y, row o) differ on few bits; squeezed to
+// those bits they index a bitmap, and a key's rank is the number of set bits below its own.
+// runs: up to 4 (lo, width) runs of varying bits, least significant first, `bits` wide in all (<= 28).
+struct RankBits {
+    uint32_t n_runs, bits;
+    uint32_t lo[4], width[4];
+};
+// workspace: 2 * 2^bits / 32 + 2^bits / 32 / 4096 + 2 words
+size_t ipx_rank_bitmap_workspace_bytes(uint32_t bits);
+hipError_t ipx_launch_rank_by_bitmap(hipStream_t s, uint32_t n_valid, const uint4 *rank_items, const RankBits &rb,
+                                     uint32_t *workspace, uint32_t *ijunc);
 hipError_t ipx_launch_find_genome_error(hipStream_t s, uint32_t n_j, const unsigned long long *first,
                                         const uint32_t *jmotif, const uint32_t *jrank,
                                         const uint32_t *jstart, const uint32_t *jend,

@@ -24,6 +24,7 @@
 // coalesced rounds of 64; segment ids come from per-chunk head counts that were
 // prefix-summed once (k_count_heads + scan), so no per-record id array is stored.
 #include "ipx_common.h"
+#include "ipx_reduce.h"
 
 namespace {
 
@@ -568,6 +569,46 @@ __global__ __launch_bounds__(256) void k_emit_ijunc(uint32_t n, const uint4 *__r
     if (i < n) ijunc[items[i].w] = i;
 }
 
+// ---- ijunc by bitmap ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t squeeze_rank_key(const uint4 &it, const RankBits &rb) {
+    const uint64_t k = (uint64_t)it.x | ((uint64_t)it.y << 32);
+    uint32_t out = 0, sh = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        if (r < rb.n_runs) {
+            out |= (uint32_t)((k >> rb.lo[r]) & ((1ull << rb.width[r]) - 1ull)) << sh;
+            sh += rb.width[r];
+        }
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_rank_mark(uint32_t n, const uint4 *__restrict__ items, RankBits rb,
+                                                   uint32_t *__restrict__ bitmap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t k = squeeze_rank_key(items[i], rb);
+        atomicOr(&bitmap[k >> 5], 1u << (k & 31u));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rank_popc(uint32_t n_words, const uint32_t *__restrict__ bitmap,
+                                                   uint32_t *__restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) counts[i] = (uint32_t)__popc(bitmap[i]);
+}
+
+__global__ __launch_bounds__(256) void k_rank_lookup(uint32_t n, const uint4 *__restrict__ items, RankBits rb,
+                                                     const uint32_t *__restrict__ bitmap,
+                                                     const uint32_t *__restrict__ before, uint32_t *__restrict__ ijunc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint4 it = items[i];
+        const uint32_t k = squeeze_rank_key(it, rb);
+        ijunc[it.w] = before[k >> 5] + (uint32_t)__popc(bitmap[k >> 5] & ((1u << (k & 31u)) - 1u));
+    }
+}
+
 // after a genome error: which key did the failing record belong to?
 __global__ __launch_bounds__(256) void k_find_genome_error(uint32_t n_j,
                                                            const unsigned long long *__restrict__ first,
@@ -586,7 +627,6 @@ __global__ __launch_bounds__(256) void k_find_genome_error(uint32_t n_j,
 }  // namespace
 
 // ---- launch wrappers (host side of this translation unit) ----------------------
-#include "ipx_reduce.h"
 
 static inline dim3 grid1d(uint64_t n, uint32_t per_block) { return dim3((uint32_t)ipx_div_up(n ? n : 1, per_block)); }
 
@@ -659,6 +699,26 @@ hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *_
     if (n_valid == 0) return hipSuccess;
     hipLaunchKernelGGL(k_emit_ijunc, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, items, ijunc);
     ipx_prof_mark(s, IPXK_EMIT_IJUNC);
+    return hipGetLastError();
+}
+
+size_t ipx_rank_bitmap_workspace_bytes(uint32_t bits) {
+    const uint64_t words = bits > 5 ? (1ull << (bits - 5)) : 1ull;
+    return (size_t)((2 * words + ipx_div_up(words, 4096) + 2) * sizeof(uint32_t));
+}
+
+hipError_t ipx_launch_rank_by_bitmap(hipStream_t s, uint32_t n_valid, const uint4 *rank_items, const RankBits &rb,
+                                     uint32_t *workspace, uint32_t *ijunc) {
+    if (n_valid == 0) return hipSuccess;
+    const uint32_t words = rb.bits > 5 ? (1u << (rb.bits - 5)) : 1u;
+    uint32_t *bitmap = workspace, *before = workspace + words, *sums = before + words;
+    hipError_t e;
+    if ((e = hipMemsetAsync(bitmap, 0, (size_t)words * sizeof(uint32_t), s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rank_mark, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, rank_items, rb, bitmap);
+    hipLaunchKernelGGL(k_rank_popc, grid1d(words, 256), dim3(256), 0, s, words, bitmap, before);
+    if ((e = ipx_launch_scan_u32(s, before, before, words, sums, nullptr)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rank_lookup, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, rank_items, rb, bitmap, before, ijunc);
+    ipx_prof_mark(s, IPXK_RANK_SORT);
     return hipGetLastError();
 }
 

@@ -335,6 +335,21 @@ def test_long_cigar_kernel_errors_and_wide_offsets():
     assert dev["error"].read_index == err.index and dev["error"].detail == err.msg
 
 
+def test_ijunc_by_radix_sort_when_the_bitmap_does_not_apply(monkeypatch):
+    """ijunc normally comes from a bitmap over the squeezed creation-order keys; IPX_RANK=sort forces
+    the radix sort that serves keys with more than 28 varying bits or more than four runs of them."""
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_RANK", "sort")
+    batch, names, _ = synth.short_reads(40_000, seed=81, n_targets=3, target_len=4_000_000, n_sites=900)
+    dev, ora, err = _run_both(batch, names, {}, n_push=2)
+    assert err is None
+    helpers.compare_tables(dev, ora)
+    batch, names, _ = synth.long_reads(600, seed=82, n_targets=2, target_len=9_000_000, n_transcripts=30)
+    dev, ora, err = _run_both(batch, names, {"max_anchor_indel_size": 36})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
 def test_per_operation_scan_kernel_matches_oracle(monkeypatch):
     """ipx_scan_ops.hip (one lane per CIGAR operation, IPX_SCAN=ops) against the oracle on short,
     long and quirk inputs; it must also fall back cleanly on a CIGAR array that is not laid out

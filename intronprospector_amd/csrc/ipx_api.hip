@@ -17,6 +17,10 @@
 
 namespace {
 
+// entries of each of the two lists that close the gaps between the record stripes (ipx_scan.hip); a
+// balanced launch leaves a few tens of thousands
+static const uint64_t CLOSE_CAP = 1u << 20;
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -110,7 +114,7 @@ struct ipx_handle {
     // holds records; an empty handle takes `first_hint`: the window the last sort would have liked
     // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
     DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
-    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg;
+    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
     void *pin_out = nullptr, *pin_out2 = nullptr;
@@ -137,6 +141,19 @@ int fail_hip(ipx_handle *h, hipError_t e, const char *what, int line) {
         return h->err.status;
     }
     return IPX_EDEVICE;
+}
+
+// Waiting for the stream: the pipeline reads a few words back between its stages (record count and key
+// masks after the scan, segment counts after the sort, table sizes at the end), each a wait of well under
+// a millisecond.  Polling hipStreamQuery returns sooner than the blocking hipStreamSynchronize (which may
+// sleep until an interrupt); IPX_SYNC=block keeps the blocking wait.
+static hipError_t ipx_stream_wait(hipStream_t s) {
+    static const bool block = [] { const char *e = getenv("IPX_SYNC"); return e && e[0] == 'b'; }();
+    if (block) return hipStreamSynchronize(s);
+    hipError_t e;
+    while ((e = hipStreamQuery(s)) == hipErrorNotReady) {
+    }
+    return e;
 }
 
 #define HIPCHK(call)                                                  \
@@ -228,7 +245,7 @@ int rebuild_ranks(ipx_handle *h) {
         }
         if ((rc = upload(h, h->d_seq_of_rank, sor.data(), sor.size() * sizeof(int32_t)))) return rc;
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     return IPX_OK;
 }
 
@@ -239,7 +256,7 @@ int reset_counters(ipx_handle *h) {
     for (int k = 0; k < 3; ++k) { c.key_or[k] = 0; c.key_and[k] = ~0u; h->key_or[k] = 0; h->key_and[k] = ~0u; }
     h->err_word_host = IPX_ERRW_NONE;
     HIPCHK(hipMemcpyAsync(h->counters.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     return IPX_OK;
 }
 
@@ -316,7 +333,9 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
     if (hipHostMalloc(&h->pin_small, 4096, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
-    int rc = ensure(h, h->counters, 256);      // Counters + ipx_scan.hip's copy of the CIGAR tail at byte 128
+    int rc = ensure(h, h->counters, IPX_COUNTERS_BYTES);      // layout: ipx_common.h
+    if (!rc && hipMemsetAsync(h->counters.p, 0, IPX_COUNTERS_BYTES, h->stream) != hipSuccess) rc = IPX_EDEVICE;
+    if (!rc) rc = ensure(h, h->close_ws, 2 * CLOSE_CAP * sizeof(unsigned long long));
     if (!rc) rc = ensure(h, h->d_small, 64 * sizeof(uint32_t));
     if (!rc) rc = reset_counters(h);
     if (!rc) rc = rebuild_ranks(h);
@@ -332,7 +351,7 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
-                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg})
+                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -397,7 +416,7 @@ int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names
     if ((rc = upload(h, h->d_seq_len, h->glen.data(), n_seqs * sizeof(int64_t)))) return rc;
     if ((rc = upload(h, h->d_seq_word2, w2.data(), n_seqs * sizeof(uint64_t)))) return rc;
     if ((rc = upload(h, h->d_seq_wordm, wm.data(), n_seqs * sizeof(uint64_t)))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));      // caller memory is borrowed until return
+    HIPCHK(ipx_stream_wait(h->stream));      // caller memory is borrowed until return
     return rebuild_ranks(h);
 }
 
@@ -476,7 +495,8 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     before.err_word = h->err_word_host;
     for (int k = 0; k < 3; ++k) { before.key_or[k] = h->key_or[k]; before.key_and[k] = h->key_and[k]; }
     bool use_ops = !h->force_lane_scan;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    bool use_stripes = true;
+    for (int attempt = 0; attempt < 5; ++attempt) {
         ipx_prof_mark(h->stream, IPXK_BEGIN);
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         if (use_ops)
@@ -484,14 +504,16 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
                                        h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
         else
             HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                   h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
+                                   h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
+                                   h->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(ipx_stream_wait(h->stream));
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
         const bool layout_bad = use_ops && c->pad[0] != 0;
-        if (!layout_bad && c->n_records <= h->rec_cap) {
+        const bool stripes_bad = c->pad[1] != 0;           // more gaps between the stripes than the lists hold
+        if (!layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->err_word_host = c->err_word;
             h->seen_words += nw;
@@ -499,14 +521,15 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
             h->n_records = c->n_records;
             break;
         }
-        if (attempt == 3) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
+        if (attempt == 4) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
         // Either the per-operation scan cannot walk this CIGAR layout (words not back to back in
         // alignment order): repeat with the lane-per-alignment kernel.  Or the capacity estimate was
         // too small: records beyond it were counted but not stored; make room and scan again.
         const uint64_t need = c->n_records;
         HIPCHK(hipMemcpyAsync(h->counters.p, &before, sizeof before, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(ipx_stream_wait(h->stream));
         if (layout_bad) use_ops = false;
+        else if (stripes_bad) use_stripes = false;
         else if ((rc = grow_records(h, need))) return rc;
     }
     (void)hipEventElapsedTime(&h->push_ms, h->ev[0], h->ev[1]);
@@ -600,7 +623,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
         }
         HIPCHK(hipMemcpyAsync(small, tot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(ipx_stream_wait(s));
         h->prof.collect();
         ipx_prof_mark(s, IPXK_BEGIN);
         J = small[0];
@@ -654,7 +677,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
                                  h->counters.as<Counters>()));
         HIPCHK(hipMemcpyAsync(small, rb.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(small + 8, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(ipx_stream_wait(s));
         h->prof.collect();
         ipx_prof_mark(s, IPXK_BEGIN);
         n_valid = small[0];
@@ -698,7 +721,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         }
     } else {
         HIPCHK(hipMemcpyAsync(small + 4, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(ipx_stream_wait(s));
         err_word = ((const Counters *)(small + 4))->err_word;
     }
 
@@ -714,7 +737,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         t.motif = rb.out_motif; t.read_counts = rb.out_read_counts; t.creator_order = rb.out_creator_order;
         t.ijunc = rb.out_ijunc; t.hist_begin = rb.out_hist_begin; t.hist_value = rb.out_hist_value;
         t.hist_count = rb.out_hist_count;
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(ipx_stream_wait(s));
     } else {
         // pinned host copy, same section layout
         Arena ha;
@@ -758,7 +781,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             D2H(p_hv, rb.out_hist_value, n_hist, uint16_t);
             D2H(p_hc, rb.out_hist_count, n_hist, uint32_t);
 #undef D2H
-            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(ipx_stream_wait(s));
             t.target = p_target; t.intron_start = p_is; t.intron_end = p_ie; t.anchor_start = p_as;
             t.anchor_end = p_ae; t.strand = p_strand; t.motif = p_motif; t.read_counts = p_counts;
             t.creator_order = p_creator; t.ijunc = p_ijunc; t.hist_begin = p_hb; t.hist_value = p_hv;
@@ -913,7 +936,7 @@ int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64
     std::vector<uint32_t> items(4 * n), pays(4 * n);
     HIPCHK(hipMemcpyAsync(items.data(), h->items_a.p, n * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pays.data(), h->pays.p, n * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     for (uint64_t i = 0; i < n; ++i) {
         const uint32_t *it = &items[4 * i];
         const uint32_t *py = &pays[4 * (uint64_t)it[3]];         // item.w = index of the record's payload
@@ -937,7 +960,7 @@ int ipx_records_sample(ipx_handle *h, uint32_t n_samples, uint64_t *out_keys) {
     HIPCHK(ipx_launch_sample(h->stream, h->items_a.as<uint4>(), h->n_records, h->key, n_samples,
                              h->d_xchg.as<unsigned long long>()));
     HIPCHK(hipMemcpyAsync(out_keys, h->d_xchg.p, (size_t)n_samples * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     return IPX_OK;
 }
 
@@ -958,7 +981,7 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
     HIPCHK(hipMemcpyAsync(d_spl, host, sizeof host, hipMemcpyHostToDevice, h->stream));
     HIPCHK(ipx_launch_partition_count(h->stream, h->items_a.as<uint4>(), h->n_records, h->key, n_parts, d_spl, d_cnt));
     HIPCHK(hipMemcpyAsync(h->pin_small, d_cnt, 64 * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     h->prof.collect();
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     const unsigned long long *c = (const unsigned long long *)h->pin_small;
@@ -971,7 +994,7 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
     HIPCHK(hipMemcpyAsync(d_cnt, host + 64, 64 * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(ipx_launch_partition_scatter(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->n_records, h->key,
                                         n_parts, d_spl, d_cnt, (uint4 *)dst_records));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     h->prof.collect();
     return IPX_OK;
 }
@@ -991,7 +1014,7 @@ int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n
     HIPCHK(ipx_launch_adopt(h->stream, (const uint4 *)records, n, 0, h->items_a.as<uint4>(), h->pays.as<uint4>(),
                             h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>()));
     HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     h->prof.collect();
     const Counters *c = (const Counters *)h->pin_small;
     for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
@@ -1005,7 +1028,7 @@ int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes) {
     (void)hipSetDevice(h->params.device);
     if (!bytes) return IPX_OK;
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(ipx_stream_wait(h->stream));
     return IPX_OK;
 }
 

@@ -64,7 +64,19 @@ struct ScanParams {
     uint32_t n_targets;
     KeyLayout key;
     DigitSpec first;      // window of the digit bytes written next to the records (the first sort pass)
+    // Where a launch's records go.  n_stripes == 0: appended at Counters::n_records.  n_stripes == 8: the
+    // launch fills IPX_STRIPES interleaved stripes after the `base` records the handle already holds, one
+    // counter per stripe (a block uses the stripe of the XCD it runs on): one returning atomic per tile
+    // on a single word saturates at ~60-90 M/s, eight words on eight lines do not.  ipx_launch_scan then
+    // closes the gaps the stripes leave, so everybody else sees base + n dense records.
+    uint64_t base;
+    uint32_t n_stripes;
 };
+constexpr uint32_t IPX_STRIPES = 8;
+constexpr uint32_t IPX_STRIPE_CHUNK_BITS = 11;       // 2048 records: stripe s owns chunks s, s + 8, s + 16, ...
+// The Counters allocation (2 KiB): Counters at 0, the copy of the CIGAR array's tail at 128 (ipx_scan.hip),
+// stripe counters at 256 + 128 * s, gap-closing counters at 1280 / 1408.
+constexpr uint32_t IPX_COUNTERS_BYTES = 2048, IPX_CNT_TAIL = 128, IPX_CNT_STRIPE0 = 256, IPX_CNT_CLOSE = 1280;
 
 // device-side counters of one handle (one cache line apart is not needed: they
 // are touched once per wave at most)
@@ -183,9 +195,12 @@ void ipx_prof_mark(hipStream_t s, int id);
 
 // ---- launchers implemented in the kernel translation units -------------------
 // ipx_scan.hip
-hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
+// p.n_stripes / p.base are set by the launcher (striped when the grid is large and close_ws is given;
+// close_ws: room for 2 * close_cap 64-bit entries)
+hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
-                           uint64_t capacity, Counters *counters);
+                           uint64_t capacity, Counters *counters, uint64_t n_records_before,
+                           unsigned long long *close_ws, uint64_t close_cap);
 
 // ipx_scan_ops.hip: the same scan with one lane per CIGAR operation (needs back-to-back CIGAR
 // words; raises Counters::pad[0] otherwise and the caller re-runs ipx_launch_scan)

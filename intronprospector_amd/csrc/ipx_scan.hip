@@ -69,6 +69,23 @@ __device__ __forceinline__ bool qc_pass(const ScanParams &p, const ReadCtx &c, c
 
 struct KeyBits { uint32_t o0, o1, o2, a0, a1, a2; };
 
+// ---- where records go (ScanParams::base / n_stripes, ipx_common.h) -------------------------------
+__device__ __forceinline__ uint32_t my_stripe(const ScanParams &p) {
+    // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on.  Any value is correct; the XCD's own
+    // keeps a stripe's counter line in one place.
+    return p.n_stripes ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & (IPX_STRIPES - 1)) : 0u;
+}
+__device__ __forceinline__ unsigned long long *append_counter(Counters *c, const ScanParams &p, uint32_t stripe) {
+    return p.n_stripes ? reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c) + IPX_CNT_STRIPE0 + 128 * stripe)
+                       : &c->n_records;
+}
+// record index of the i-th record of a stripe (i as returned by the stripe's counter)
+__device__ __forceinline__ uint64_t append_index(const ScanParams &p, uint32_t stripe, uint64_t i) {
+    if (!p.n_stripes) return i;
+    const uint64_t chunk = (i >> IPX_STRIPE_CHUNK_BITS) * IPX_STRIPES + stripe;
+    return p.base + ((chunk << IPX_STRIPE_CHUNK_BITS) | (i & ((1u << IPX_STRIPE_CHUNK_BITS) - 1)));
+}
+
 // key (item.x/y/z; item.w is left 0) and payload words of one record
 __device__ __forceinline__ void pack_record(const ScanParams &p, const ReadCtx &c, const Rec &r,
                                             uint32_t ordinal, uint4 &item, uint4 &pay) {
@@ -138,8 +155,8 @@ struct Pool {                    // LDS staging of a tile's records (k_scan_pool
     uint32_t cap;
 };
 
-// MODE 0: count; MODE 1: store at slot0 + ordinal in the global record arrays; MODE 2: append to the LDS pool;
-// MODE 3: records with ordinal >= slot0 each reserve their own slot of the global arrays (k_scan_long's rare re-run)
+// MODE 0: count; MODE 1: store at slot0 + ordinal of the stripe; MODE 2: append to the LDS pool;
+// MODE 3: records with ordinal >= slot0 each reserve their own slot of the stripe (k_scan_long's rare re-run)
 template <int MODE>
 __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx &c,
                                              const uint32_t *__restrict__ cig, uint32_t nc,
@@ -147,7 +164,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
                                              uint8_t *__restrict__ digs, KeyBits &kb,
                                              unsigned long long &err, const Pool *pool = nullptr,
-                                             unsigned long long *n_records = nullptr) {
+                                             unsigned long long *n_records = nullptr, uint32_t stripe = 0) {
     uint32_t state = ST_LIMBO;
     int64_t target_pos = c.pos, anchor_start = -1, intron_start = -1, intron_end = -1, anchor_end = -1;
     uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
@@ -156,11 +173,11 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
         const Rec r{anchor_start, intron_start, intron_end, anchor_end, lmm, rmm, lind, rind};
         if (qc_pass(p, c, r)) {
             if (MODE == 1) {
-                const uint64_t idx = slot0 + ordinal;
+                const uint64_t idx = append_index(p, stripe, slot0 + ordinal);
                 if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
             } else if (MODE == 3) {
                 if (ordinal >= slot0 && ordinal <= IPX_ORD_MAX_ORDINAL) {
-                    const uint64_t idx = atomicAdd(n_records, 1ull);
+                    const uint64_t idx = append_index(p, stripe, atomicAdd(n_records, 1ull));
                     if (idx < capacity) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
                 }
             } else if (MODE == 2) {
@@ -239,198 +256,6 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
         err = e < err ? e : err;
     }
     return ordinal;
-}
-
-// One block = one tile of 256*RPT consecutive alignments, thread t takes alignments
-// tile + r*256 + t.  Pass 1 counts each alignment's records, a block scan turns the
-// counts into slots (round-major, so that at a fixed r neighbouring lanes own
-// neighbouring slots and the record stores coalesce), ONE atomicAdd per tile reserves
-// the tile's range of the record arrays, pass 2 re-runs the state machines and stores.
-// (One returning atomic per wave and step on a single counter serialises at ~17 ns each:
-// that version spent 5.4 ms on 10 M alignments; the CIGAR words of a tile are re-read
-// from L1/L2.)
-template <uint32_t RPT, uint32_t POOL>
-__global__ __launch_bounds__(256) void k_scan(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
-                                              const int32_t *__restrict__ a_tid,
-                                              const int32_t *__restrict__ a_pos,
-                                              const uint16_t *__restrict__ a_flag,
-                                              const uint8_t *__restrict__ a_xs,
-                                              const uint8_t *__restrict__ a_nh,
-                                              const uint32_t *__restrict__ a_off,
-                                              const uint32_t *__restrict__ a_nc,
-                                              const uint32_t *__restrict__ cigar,
-                                              const uint32_t *__restrict__ rank_of_tid,
-                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                              uint8_t *__restrict__ digs,
-                                              uint64_t capacity, Counters *counters) {
-    __shared__ uint32_t wsum[RPT][4];
-    __shared__ uint32_t kb_s[4][6];
-    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
-    __shared__ uint32_t cnt_s[RPT][256], base_s[RPT][256];
-    __shared__ unsigned long long tile_slot;
-    // POOL > 0: a tile's records are first staged in LDS by ONE run of the state machines and then
-    // copied out as a block (no second run); a tile that emits more than POOL records falls back to
-    // the count / reserve / re-run scheme below
-    __shared__ uint4 pool_item[POOL ? POOL : 1], pool_pay[POOL ? POOL : 1];
-    __shared__ uint32_t pool_n;
-    const Pool pool{pool_item, pool_pay, &pool_n, POOL};
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t n_tiles = (n + 256ull * RPT - 1) / (256ull * RPT);
-
-    // per-alignment attributes; re-read in pass 2 (L1/L2 hits) instead of held in registers
-    auto load_ctx = [&](uint64_t i, ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
-        c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = base_read_index + i;
-        nc = 0; off = 0;
-        if (i < n) {
-            const int32_t tid = a_tid[i];
-            c.flag = a_flag[i];
-            nc = a_nc[i];
-            // junctions_extractor.cc:536
-            if (nc <= 1 || tid < 0 || (c.flag & (F_QCFAIL | F_DUP))) nc = 0;
-            if (nc) {
-                if ((uint32_t)tid >= p.n_targets) {
-                    const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
-                    err = e < err ? e : err;
-                    nc = 0;
-                } else {
-                    c.pos = a_pos[i];
-                    off = a_off[i];
-                    if ((uint64_t)off + nc > n_words) {          // words outside the batch: never dereferenced
-                        const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
-                        err = e < err ? e : err;
-                        nc = 0;
-                    }
-                    c.nhc = a_nh[i];
-                    c.rank = rank_of_tid[tid];
-                    const uint32_t xs = a_xs[i];
-                    c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
-                                                                : (xs ? xs : (uint32_t)'.');
-                }
-            }
-        }
-        c.cat = read_category(c.flag, c.nhc);
-        c.read_rejected = (c.flag & F_SECONDARY) || (p.exclude_multi && c.nhc == 2);
-    };
-
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        unsigned long long my_err = IPX_ERRW_NONE;
-        if (POOL) {
-            if (t == 0) pool_n = 0;
-            __syncthreads();
-#pragma unroll 1
-            for (uint32_t r = 0; r < RPT; ++r) {
-                const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
-                ReadCtx c;
-                uint32_t nc, off;
-                load_ctx(i, c, nc, off, my_err);
-                if (nc) (void)run_read<2>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err, &pool);
-            }
-            __syncthreads();
-            const uint32_t total = pool_n;
-            if (total <= POOL) {
-                if (t == 0) tile_slot = total ? atomicAdd(&counters->n_records, (unsigned long long)total) : 0ull;
-                __syncthreads();
-                const uint64_t slot = tile_slot;
-                for (uint32_t k = t; k < total; k += 256) {
-                    const uint64_t idx = slot + k;
-                    if (idx < capacity) {
-                        uint4 it = pool_item[k];
-                        it.w = (uint32_t)idx;
-                        items[idx] = it;
-                        pays[idx] = pool_pay[k];
-                        digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
-                        kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
-                        kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
-                    }
-                }
-                unsigned long long e = my_err;
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const unsigned long long o = __shfl_xor(e, d);
-                    e = o < e ? o : e;
-                }
-                if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
-                __syncthreads();
-                continue;
-            }
-        }
-        // pass 1: count.  Loops over r stay rolled (one copy of the state machine in the
-        // code, low register pressure); per-round counts live in LDS.
-#pragma unroll 1
-        for (uint32_t r = 0; r < RPT; ++r) {
-            const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
-            ReadCtx c;
-            uint32_t nc, off;
-            load_ctx(i, c, nc, off, my_err);
-            const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err) : 0;
-            cnt_s[r][t] = cn;
-            // inclusive scan inside the wave
-            uint32_t v = cn;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t x = __shfl_up(v, o);
-                if ((int)lane >= o) v += x;
-            }
-            base_s[r][t] = v - cn;                   // exclusive inside the wave, completed below
-            if (lane == 63) wsum[r][wave] = v;
-        }
-        __syncthreads();
-        uint32_t tile_total = 0;
-#pragma unroll 1
-        for (uint32_t r = 0; r < RPT; ++r) {
-            uint32_t before = tile_total;
-            for (uint32_t w = 0; w < 4; ++w) {
-                const uint32_t sw = wsum[r][w];
-                if (w < wave) before += sw;
-                tile_total += sw;
-            }
-            base_s[r][t] += before;
-        }
-        if (t == 0) tile_slot = tile_total ? atomicAdd(&counters->n_records, (unsigned long long)tile_total) : 0ull;
-        __syncthreads();
-        const uint64_t slot = tile_slot;
-        if (tile_total) {
-#pragma unroll 1
-            for (uint32_t r = 0; r < RPT; ++r) {
-                if (cnt_s[r][t]) {
-                    const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
-                    unsigned long long dummy = IPX_ERRW_NONE;
-                    ReadCtx c;
-                    uint32_t nc, off;
-                    load_ctx(i, c, nc, off, dummy);
-                    (void)run_read<1>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy);
-                }
-            }
-        }
-        // earliest error of the wave -> one atomic
-        unsigned long long e = my_err;
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(e, d);
-            e = o < e ? o : e;
-        }
-        if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
-        __syncthreads();          // tile_slot / wsum are reused by the next tile
-    }
-    // OR / AND of every key this block stored -> six atomics per block
-    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-            const uint32_t o = __shfl_xor(v[k], dlt);
-            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
-        }
-        if (lane == 0) kb_s[wave][k] = v[k];
-    }
-    __syncthreads();
-    if (t < 6) {
-        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
-        if (t < 3) {
-            const uint32_t o = x0 | x1 | x2 | x3;
-            if (o) atomicOr(&counters->key_or[t], o);
-        } else {
-            const uint32_t a = x0 & x1 & x2 & x3;
-            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
-        }
-    }
 }
 
 // ---- long CIGARs ---------------------------------------------------------------------------------
@@ -518,14 +343,15 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
     if (next > n) next = n;
     uint32_t staged = 0, staged_used = 0;         // alignments in the stage / already handed out
     uint32_t pool_n = 0;
+    const uint32_t stripe = my_stripe(p);
 
     auto flush = [&]() {
         __threadfence_block();
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&counters->n_records, (unsigned long long)pool_n);
+        if (lane == 0) base = atomicAdd(append_counter(counters, p, stripe), (unsigned long long)pool_n);
         base = __shfl(base, 0);
         for (uint32_t k = lane; k < pool_n; k += 64) {
-            const uint64_t idx = base + k;
+            const uint64_t idx = append_index(p, stripe, base + k);
             if (idx < capacity) {
                 uint4 it = my_item[k];
                 it.w = (uint32_t)idx;
@@ -675,7 +501,7 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
                 c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
                 c.read_index = base_read_index + my_i;
                 (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, digs, kb,
-                                  my_err, nullptr, &counters->n_records);
+                                  my_err, nullptr, append_counter(counters, p, stripe), stripe);
                 redo = false;
             }
         }
@@ -831,6 +657,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
     const Pool pool{pool_item, pool_pay, &pool_n, POOL};
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + 256ull * RPT - 1) / (256ull * RPT);
+    const uint32_t stripe = my_stripe(p);
 
     auto load_ctx = [&](uint64_t i, ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
         c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = base_read_index + i;
@@ -995,11 +822,11 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
         __syncthreads();
         const uint32_t total = pool_n;
         if (total <= POOL) {
-            if (t == 0) tile_slot = total ? atomicAdd(&counters->n_records, (unsigned long long)total) : 0ull;
+            if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;
             for (uint32_t k = t; k < total; k += 256) {
-                const uint64_t idx = slot + k;
+                const uint64_t idx = append_index(p, stripe, slot + k);
                 if (idx < capacity) {
                     uint4 it = pool_item[k];
                     it.w = (uint32_t)idx;
@@ -1042,7 +869,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
                 }
                 base_s[r][t] += before;
             }
-            if (t == 0) tile_slot = tile_total ? atomicAdd(&counters->n_records, (unsigned long long)tile_total) : 0ull;
+            if (t == 0) tile_slot = tile_total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)tile_total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;
 #pragma unroll 1
@@ -1053,7 +880,8 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
                     ReadCtx c;
                     uint32_t nc, off;
                     load_ctx(i, c, nc, off, dummy);
-                    (void)run_read<1>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy);
+                    (void)run_read<1>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy,
+                                      nullptr, nullptr, stripe);
                 }
             }
         }
@@ -1087,26 +915,122 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
     }
 }
 
+// ---- closing the gaps of a striped launch ---------------------------------------------------------
+// After a striped scan the launch's records sit in eight interleaved stripes behind `base`, every stripe
+// filled up to its own count: all positions below the shortest stripe's last full round of chunks are
+// taken, the rest of the range has holes.  k_close_find lists the holes below base + n and the records at
+// or above it (equally many), k_close_move pairs them off, k_close_finish publishes base + n as the
+// record count and zeroes the stripe counters for the next launch.  A launch that ran out of capacity
+// publishes the extent it would have needed instead (the caller grows the arrays and repeats the scan).
+struct StripeState {
+    unsigned long long count[IPX_STRIPES];
+    unsigned long long n, extent, window_lo;
+};
+
+__device__ __forceinline__ StripeState stripe_state(const Counters *counters) {
+    StripeState st;
+    st.n = 0;
+    st.extent = 0;
+    unsigned long long rounds = ~0ull;
+    for (uint32_t k = 0; k < IPX_STRIPES; ++k) {
+        const unsigned long long c = *reinterpret_cast<const unsigned long long *>(
+            reinterpret_cast<const char *>(counters) + IPX_CNT_STRIPE0 + 128 * k);
+        st.count[k] = c;
+        st.n += c;
+        if (c) {
+            const unsigned long long last = c - 1;
+            const unsigned long long end = ((((last >> IPX_STRIPE_CHUNK_BITS) * IPX_STRIPES + k) << IPX_STRIPE_CHUNK_BITS) |
+                                            (last & ((1u << IPX_STRIPE_CHUNK_BITS) - 1))) + 1;
+            st.extent = end > st.extent ? end : st.extent;
+        }
+        const unsigned long long full = c >> IPX_STRIPE_CHUNK_BITS;
+        rounds = full < rounds ? full : rounds;
+    }
+    st.window_lo = (rounds * IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS;
+    return st;
+}
+
+__global__ __launch_bounds__(256) void k_close_find(Counters *counters, uint64_t base, uint64_t capacity,
+                                                    unsigned long long *__restrict__ holes,
+                                                    unsigned long long *__restrict__ tails, uint64_t list_cap) {
+    const StripeState st = stripe_state(counters);
+    if (base + st.extent > capacity || st.extent == st.n) return;
+    unsigned long long *n_holes = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_CLOSE);
+    unsigned long long *n_tails = n_holes + 16;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p0 = st.window_lo + (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); p0 < st.extent; p0 += stride) {
+        const uint64_t pos = p0 + lane;
+        const uint64_t chunk = pos >> IPX_STRIPE_CHUNK_BITS;
+        const uint32_t k = (uint32_t)(chunk & (IPX_STRIPES - 1));
+        const uint64_t i = ((chunk / IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS) | (pos & ((1u << IPX_STRIPE_CHUNK_BITS) - 1));
+        const bool taken = pos < st.extent && i < st.count[k];
+        const bool hole = pos < st.n && !taken, tail = pos >= st.n && taken;
+        const unsigned long long hm = __ballot(hole), tm = __ballot(tail);
+        if (hm) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(n_holes, (unsigned long long)__popcll(hm));
+            at = __shfl(at, 0) + (unsigned long long)__popcll(hm & ((1ull << lane) - 1ull));
+            if (hole && at < list_cap) holes[at] = pos;
+        }
+        if (tm) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(n_tails, (unsigned long long)__popcll(tm));
+            at = __shfl(at, 0) + (unsigned long long)__popcll(tm & ((1ull << lane) - 1ull));
+            if (tail && at < list_cap) tails[at] = pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_close_move(const Counters *counters, uint64_t base,
+                                                    const unsigned long long *__restrict__ holes,
+                                                    const unsigned long long *__restrict__ tails, uint64_t list_cap,
+                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                                    uint8_t *__restrict__ digs) {
+    const unsigned long long n = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(counters) + IPX_CNT_CLOSE);
+    if (n > list_cap) return;                       // reported by k_close_finish
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t src = base + tails[i], dst = base + holes[i];
+        uint4 it = items[src];
+        it.w = (uint32_t)dst;
+        items[dst] = it;
+        pays[dst] = pays[src];
+        digs[dst] = digs[src];
+    }
+}
+
+__global__ void k_close_finish(Counters *counters, uint64_t base, uint64_t capacity, uint64_t list_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const StripeState st = stripe_state(counters);
+    unsigned long long *n_holes = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_CLOSE);
+    if (base + st.extent > capacity) counters->n_records = base + st.extent;     // out of room: what it would take
+    else counters->n_records = base + st.n;
+    if (*n_holes > list_cap) counters->pad[1] = 1;                               // lists too short: repeat without stripes
+    for (uint32_t k = 0; k < IPX_STRIPES; ++k)
+        *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_STRIPE0 + 128 * k) = 0;
+    n_holes[0] = 0;
+    n_holes[16] = 0;
+}
+
 }  // namespace
 
-hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &b,
+hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
-                           uint64_t capacity, Counters *counters) {
+                           uint64_t capacity, Counters *counters, uint64_t n_records_before,
+                           unsigned long long *close_ws, uint64_t close_cap) {
     if (b.n_alignments == 0) return hipSuccess;
     // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
     const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;      // (the long kernel needs >= 8 words)
     const uint64_t per_tile = short_reads ? 512 : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
     if (blocks > 256ull * 16) blocks = 256ull * 16;
-    // the Counters allocation is 256 bytes; bytes 128..191 hold the copy of the array's last words
-    uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + 128);
+    uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
-    static const bool old_short = [] { const char *e = getenv("IPX_SCAN_SHORT"); return e && e[0] == 'o'; }();
-    if (short_reads && old_short)
-        hipLaunchKernelGGL((k_scan<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
-                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, rank_of_tid, items, pays, digs, capacity, counters);
-    else if (short_reads)
+    // stripes pay once many blocks queue on the record counter
+    static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
+    p.base = n_records_before;
+    p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
+    if (short_reads)
         hipLaunchKernelGGL((k_scan_short<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
@@ -1123,9 +1047,16 @@ hipError_t ipx_launch_scan(hipStream_t s, const ScanParams &p, const ipx_batch &
         // few alignments per lane: whole multiples of 64, or one lane's second alignment doubles the wave's time
         if (per_wave < 256) per_wave = (per_wave + 63) / 64 * 64;
         const uint64_t waves = ipx_div_up(b.n_alignments, per_wave);
+        p.n_stripes = (waves >= 256 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
         hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                            b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+    }
+    if (p.n_stripes) {
+        unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
+        hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);
+        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, digs);
+        hipLaunchKernelGGL(k_close_finish, dim3(1), dim3(64), 0, s, counters, p.base, capacity, close_cap);
     }
     ipx_prof_mark(s, IPXK_SCAN);
     return hipGetLastError();

@@ -1,0 +1,108 @@
+"""GPU: BASELINE.json's configurations at full size.  The oracle is fast enough (a scalar C walk
+with a hash table, tens of millions of alignments per second) to check the whole table bit for bit
+at 10 M alignments; on top of that the size-independent properties of the domain: key order,
+conservation of records, histogram sums, ijunc as the rank of the creation order, shard invariance
+(one push == several pushes == two handles merged by hand) and idempotence of finalize."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.oracle_binding import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(t):
+    h = hashlib.sha256()
+    for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "motif", "counts",
+              "creator_order", "ijunc", "hist_begin", "hist_value", "hist_count"):
+        h.update(np.ascontiguousarray(t[k]).tobytes())
+    return h.hexdigest()
+
+
+def _check_properties(t, n_alignments):
+    n = len(t["intron_start"])
+    assert t["n_alignments"] == n_alignments and n > 0
+    # std::map order: (target, start, end) strictly ascending
+    key = (t["target"].astype(np.uint64) << np.uint64(40)) | t["intron_start"].astype(np.uint64)
+    assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (t["intron_end"][1:] > t["intron_end"][:-1])))
+    # without a filter every QC-passed record is counted exactly once
+    assert int(t["counts"].sum()) == int(t["n_records"])
+    # histogram: CSR, counts sum to the junction's reads, offsets ascending inside a junction
+    hb = t["hist_begin"].astype(np.int64)
+    assert hb[0] == 0 and hb[-1] == len(t["hist_value"]) == len(t["hist_count"])
+    assert np.all(hb[1:] > hb[:-1])
+    per_j = np.add.reduceat(t["hist_count"].astype(np.int64), hb[:-1])
+    assert np.array_equal(per_j, t["counts"].sum(axis=1).astype(np.int64))
+    inner = np.ones(len(t["hist_value"]), bool)
+    inner[hb[:-1]] = False
+    v = t["hist_value"].astype(np.int64)
+    assert np.all(v[1:][inner[1:]] > v[:-1][inner[1:]])
+    # ijunc: a permutation, and the rank of the creation order
+    assert np.array_equal(np.sort(t["ijunc"]), np.arange(n, dtype=t["ijunc"].dtype))
+    assert np.array_equal(np.argsort(t["creator_order"], kind="stable"), np.argsort(t["ijunc"], kind="stable"))
+    assert np.all(t["anchor_start"] < t["intron_start"]) and np.all(t["anchor_end"] > t["intron_end"])
+
+
+def _run(batch, names, n_push=1, **params):
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    ex = ipa.JunctionsExtractor(targets=names, **params)
+    n = len(batch["tid"])
+    cuts = np.linspace(0, n, n_push + 1).astype(int)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ex.push(synth.slice_batch(batch, int(a), int(b)))
+    t = ex.get_junctions()
+    t2 = ex.get_junctions()                       # idempotence
+    ex.close()
+    assert _digest(t) == _digest(t2)
+    return t
+
+
+def test_config_S_10M_short_reads():
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(10_000_000, seed=synth.SEED_S)
+    t1 = _run(batch, names)
+    _check_properties(t1, 10_000_000)
+    assert _digest(_run(batch, names, n_push=3)) == _digest(t1)          # shard invariance
+    ora = Oracle(targets=names)
+    ora.process(batch)
+    helpers.compare_tables(t1, ora.table())
+    ora.close()
+
+
+def test_config_L_long_reads():
+    from intronprospector_amd import synth
+    batch, names, _ = synth.long_reads(200_000, seed=synth.SEED_L)
+    p = {"max_anchor_indel_size": 36}
+    t1 = _run(batch, names, **p)
+    _check_properties(t1, 200_000)
+    assert _digest(_run(batch, names, n_push=4, **p)) == _digest(t1)
+    ora = Oracle(targets=names, **p)
+    ora.process(batch)
+    helpers.compare_tables(t1, ora.table())
+    ora.close()
+
+
+def test_config_G_genome_strand_inference(tmp_path):
+    """10 M short reads over a 160 Mb synthetic genome (2-bit on the device), --sj-filter=canon."""
+    from intronprospector_amd import synth, _lib as L
+    batch, names, gen = synth.short_reads(10_000_000, seed=synth.SEED_S + 1, target_len=20_000_000, n_sites=100_000,
+                                          genome=True)
+    fa = str(tmp_path / "g.fa")
+    gen.write_fasta(fa)
+    g2 = (gen.names, [(t, m, len(s)) for (t, m), s in zip(gen.twobit(), gen.seqs)])
+    t1 = _run(batch, names, genome=g2, junction_filter=L.IPX_SJ_CANON)
+    assert "error" not in t1
+    n = len(t1["intron_start"])
+    assert n > 50_000 and int(t1["counts"].sum()) <= int(t1["n_records"])      # the filter drops records
+    ora = Oracle(targets=names, genome_fasta=fa, junction_filter=2)
+    ora.process(batch)
+
+    def fetch(tid, start, end):            # the four raw bases, as tests/test_gpu_parity.py::_fetcher
+        s = gen.seqs[tid]
+        return bytes([s[start], s[start + 1], s[end - 2], s[end - 1]])
+    helpers.compare_tables(t1, ora.table(), fetch)
+    ora.close()

@@ -335,6 +335,39 @@ def test_long_cigar_kernel_errors_and_wide_offsets():
     assert dev["error"].read_index == err.index and dev["error"].detail == err.msg
 
 
+def test_striped_append_with_uneven_stripes_and_capacity_retry():
+    """Scan launches of 64 or more blocks append through eight striped counters and close the gaps
+    afterwards (ipx_scan.hip).  Uneven stripes: all junctions come from the first tiles of a large
+    batch.  Capacity retry: a first push without junctions teaches the handle a low records-per-word
+    ratio, the second push has one junction per alignment and must regrow the record arrays."""
+    from intronprospector_amd import synth
+    import intronprospector_amd as ipa
+    spliced, names, _ = synth.short_reads(40_000, seed=91, n_targets=2, target_len=4_000_000, n_sites=700)
+    n_plain = 90_000
+    plain = {"tid": np.zeros(n_plain, np.int32), "pos": (np.arange(n_plain, dtype=np.int32) * 7 + 100),
+             "flag": np.zeros(n_plain, np.uint16), "xs": np.zeros(n_plain, np.uint8), "nh": np.ones(n_plain, np.uint8),
+             "cigar_off": (np.arange(n_plain, dtype=np.uint32) * 2), "n_cigar": np.full(n_plain, 2, np.uint32),
+             "cigar": np.tile(np.array([(60 << 4) | 0, (40 << 4) | 4], np.uint32), n_plain)}      # 60M40S: no junction
+    # uneven: junction reads first, then 90 k alignments that emit nothing (same launch, >= 64 blocks)
+    uneven = synth.concat_batches([synth.slice_batch(spliced, 0, 6000), plain])
+    dev, ora, err = _run_both(uneven, names, {})
+    assert err is None and len(ora["intron_start"]) > 30 and int(ora["counts"].sum()) > 3000
+    helpers.compare_tables(dev, ora)
+    # retry: the ratio learnt from `plain` makes the next capacity guess far too small
+    ex = ipa.JunctionsExtractor(targets=names)
+    ex.push(plain)
+    assert len(ex.get_junctions()["intron_start"]) == 0
+    ex.push(spliced)
+    ex.push(synth.slice_batch(spliced, 0, 20_000))
+    dev = ex.get_junctions()
+    ex.close()
+    o = Oracle(targets=names)
+    for b in (plain, spliced, synth.slice_batch(spliced, 0, 20_000)):
+        o.process(b)
+    helpers.compare_tables(dev, o.table())
+    o.close()
+
+
 def test_ijunc_by_radix_sort_when_the_bitmap_does_not_apply(monkeypatch):
     """ijunc normally comes from a bitmap over the squeezed creation-order keys; IPX_RANK=sort forces
     the radix sort that serves keys with more than 28 varying bits or more than four runs of them."""

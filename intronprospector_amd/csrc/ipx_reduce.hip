@@ -82,11 +82,17 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
                                                      uint32_t *__restrict__ jstart,
                                                      uint32_t *__restrict__ jend,
                                                      uint32_t *__restrict__ jfirstbin,
-                                                     uint32_t *__restrict__ bin_off) {
+                                                     uint32_t *__restrict__ bin_off,
+                                                     unsigned long long *__restrict__ first,
+                                                     unsigned long long *__restrict__ creator,
+                                                     unsigned long long *__restrict__ counts,
+                                                     uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
+                                                     uint32_t *__restrict__ bin_count, uint32_t *__restrict__ totals) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t base = chunk * CHUNK;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[2] = 0; totals[3] = 0; totals[4] = 0; totals[5] = ~0u; totals[6] = ~0u; }
     if (base >= n) return;
     uint32_t nj = chunk_j[chunk], nb = chunk_b[chunk];     // heads before this chunk
 #pragma unroll
@@ -98,7 +104,13 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
         if (h.head_b) {
             const KeyParts k = unpack_key(h.it, kl);
             bin_off[bid] = k.off16;
-            if (h.head_j) { jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; jfirstbin[jid] = bid; }
+            bin_count[bid] = 0;                  // the rows k_reduce accumulates into start at the identity
+            if (h.head_j) {
+                jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; jfirstbin[jid] = bid;
+                first[jid] = ~0ull; creator[jid] = ~0ull;
+                amin[jid] = ~0u; amax[jid] = 0u;
+                counts[3ull * jid] = 0; counts[3ull * jid + 1] = 0; counts[3ull * jid + 2] = 0;
+            }
         }
         nj += (uint32_t)__popcll(mj);
         nb += (uint32_t)__popcll(mb);
@@ -645,21 +657,12 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
     const uint32_t J = rb.n_j, B = rb.n_b;
     hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
-                       rb.jfirstbin, rb.bin_off);
+                       rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, rb.totals);
     ipx_prof_mark(s, IPXK_WRITE_HEADS);
     hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
                        rb.jstart, rb.jend, rb.jmotif);
     ipx_prof_mark(s, IPXK_MOTIF);
     hipError_t e;
-    if ((e = hipMemsetAsync(rb.first, 0xff, sizeof(uint64_t) * J, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.creator, 0xff, sizeof(uint64_t) * J, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.amin, 0xff, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.amax, 0, sizeof(uint32_t) * J, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.counts, 0, sizeof(uint64_t) * 3 * J, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.bin_count, 0, sizeof(uint32_t) * B, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.totals + 2, 0, sizeof(uint32_t) * 3, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rb.totals + 5, 0xff, sizeof(uint32_t) * 2, s)) != hipSuccess) return e;
-    ipx_prof_mark(s, IPXK_MEMSET);
     // A record can fail the filter only against a motif and under "canon" (splice_juncs.cc:52-61)
     const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
     if (!filter_active) {

@@ -32,7 +32,7 @@ AlnReader::AlnReader(const std::string &path) : path_(path) {
     } else {
         if (n == 4 && memcmp(magic, "CRAM", 4) == 0)
             throw std::runtime_error("Error opening BAM/SAM/CRAM file: " + path + " (CRAM is not supported)");
-        gzrewind(fh_);
+        if (n > 0) pushback_.assign((const char *)magic, (size_t)n);     // a pipe cannot be rewound
         parse_sam_header();
     }
 }
@@ -46,6 +46,17 @@ bool AlnReader::read(AlnRecord &rec) { return bam_ ? read_bam(rec) : read_sam(re
 // ---- SAM text ----------------------------------------------------------------
 bool AlnReader::read_line() {
     line_.clear();
+    if (!pushback_.empty()) {
+        const size_t nl = pushback_.find('\n');
+        if (nl != std::string::npos) {               // the probed bytes hold a whole (tiny) line
+            line_.assign(pushback_, 0, nl);
+            pushback_.erase(0, nl + 1);
+            while (!line_.empty() && line_.back() == '\r') line_.pop_back();
+            return true;
+        }
+        line_.swap(pushback_);
+        pushback_.clear();
+    }
     char chunk[65536];
     for (;;) {
         if (!gzgets(fh_, chunk, sizeof chunk)) return !line_.empty();

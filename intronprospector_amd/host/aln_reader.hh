@@ -60,7 +60,7 @@ private:
     std::vector<std::string> names_;
     std::vector<int64_t> lengths_;
     // SAM text state
-    std::string line_;
+    std::string line_, pushback_;            // pushback_: bytes read while probing the format
     bool have_line_ = false;
     bool read_line();
     void parse_sam_header();

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <sys/stat.h>
 #include <zlib.h>
 
 namespace ipxhost {
@@ -17,6 +18,10 @@ static bool bgzf_header_ok(const uint8_t *h) {
 }
 
 bool BgzfReader::is_bgzf(const std::string &path) {
+    // only files can be probed and reopened; a pipe (/dev/stdin) goes through zlib's gzip reader, which
+    // takes BGZF as the multi-member gzip file it is (single-threaded)
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
     uint8_t h[kHeader];

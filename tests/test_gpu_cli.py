@@ -109,6 +109,27 @@ def test_cli_pass_through_and_strand_tags(cli, golden, tmp_path):
     assert r.returncode == 1 and b"can only have one input BAM" in r.stderr
 
 
+def test_cli_reads_standard_input(cli, golden, tmp_path):
+    """No input file = /dev/stdin (src/intronProspector.cc:266-268): SAM through a pipe, BAM through a
+    pipe (zlib's gzip reader) and BAM as a redirected file (the parallel BGZF reader)."""
+    sam = os.path.join(golden, "input", "test_basic.sam")
+    bam = str(tmp_path / "b.bam")
+    bamio.sam_to_bam(sam, bam)
+    with open(os.path.join(golden, "expected", "testBasic1.introns.tsv"), "rb") as f:
+        exp = f.read()
+    for src, piped in ((sam, True), (bam, True), (bam, False)):
+        out = str(tmp_path / "o.tsv")
+        cmd = [cli, "--min-confidence-score=0.0", "--intron-calls=" + out]
+        if piped:
+            p1 = subprocess.Popen(["cat", src], stdout=subprocess.PIPE)
+            subprocess.run(cmd, stdin=p1.stdout, check=True)
+            p1.wait()
+        else:
+            with open(src, "rb") as fi:
+                subprocess.run(cmd, stdin=fi, check=True)
+        assert open(out, "rb").read() == exp, (src, piped)
+
+
 def test_cli_gzip_outputs(cli, golden, tmp_path):
     import gzip
     out = {s: str(tmp_path / ("b1." + s + ".gz")) for s in ("juncs.bed", "introns.bed", "introns.tsv")}

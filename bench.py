@@ -7,6 +7,11 @@ records) -> ipx_finalize (radix sort + segmented reduce -> junction table in
 HBM).  With N > 1 every rank holds its own contiguous shard of N x reads
 alignments (weak scaling) and the partial tables are combined over RCCL.
 
+Timing: W warm-up steps, then exactly K timed steps between barrier + synchronize.  Inside the timed
+region HIP events bracket the launches of the dominant kernel class only (roofline.avg_ms); the full
+per-kernel table (roofline.kernels_ms_per_step) comes from three further, untimed steps with events
+around every launch.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
@@ -165,9 +170,18 @@ def main():
         n_records[0] = table.n_records
         return table
 
+    # Warm-up with event pairs around every launch: tells which kernel class dominates.  The timed region
+    # then brackets the launches of that class alone (an event before and after each): pairs around all
+    # ~70 launches of a step cost a 10 M-alignment step about 10 % of its time.
+    ex.profile(True)
     for _ in range(args.warmup):
         table = step()
-    ex.profile(True)
+    torch.cuda.synchronize()
+    warm = ex.profile_read()
+    bracketed = {"k_scan", "k_scatter", "k_reduce"}
+    cand = {k: v for k, v in warm.items() if k in bracketed}
+    dominant = max(cand.items(), key=lambda kv: kv[1][1])[0] if cand else ("k_scan" if kind == "L" else "k_scatter")
+    ex.profile_only(dominant)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,6 +192,13 @@ def main():
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    timed = ex.profile_read()
+    # per-kernel breakdown: a few more steps, untimed, with event pairs around every launch
+    breakdown_steps = 3
+    ex.profile(True)
+    for _ in range(breakdown_steps):
+        table = step()
+    torch.cuda.synchronize()
     stats = ex.profile_read()
     ex.profile(False)
     if multi:
@@ -197,8 +218,8 @@ def main():
         c = n_words / n
         j = r / n
         b_alg = 20 + 4 * c + 64 * j                      # SURVEY.md 8(d), bytes per alignment
-        dev_ms = sum(v[1] for v in stats.values()) / args.steps
-        dom = max(stats.items(), key=lambda kv: kv[1][1]) if stats else None
+        dev_ms = sum(v[1] for v in stats.values()) / breakdown_steps
+        dom = (dominant, timed[dominant]) if dominant in timed else None
         roofline = None
         if dom:
             name, (launches, total_ms) = dom
@@ -220,7 +241,8 @@ def main():
                 "pipeline": {"bytes_per_alignment": b_alg, "device_ms_per_step": dev_ms,
                              "achieved": b_alg * n / (dev_ms * 1e-3) / 1e9 if dev_ms else None,
                              "frac": b_alg * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dev_ms else None},
-                "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+                # from breakdown_steps extra steps after the timed region (every launch bracketed there)
+                "kernels_ms_per_step": {k: v[1] / breakdown_steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
             }
         out = {
             "metric": "alignments/sec junction extraction", "value": value, "unit": "alignments/s",

@@ -280,6 +280,10 @@ typedef struct ipx_kernel_stat {
     double   total_ms;
 } ipx_kernel_stat;
 int ipx_profile(ipx_handle *h, int enable);     /* enable/disable, resets the sums */
+/* Time one kernel class alone ("k_scan", "k_scatter" or "k_reduce"): an event right before and right
+ * after each of its launches and nothing else -- event pairs around EVERY launch (ipx_profile) cost a
+ * 10 M-alignment step about 10 % of its time, these do not. */
+int ipx_profile_only(ipx_handle *h, const char *kernel);
 int ipx_profile_read(const ipx_handle *h, ipx_kernel_stat *out, uint32_t cap, uint32_t *n);
 
 #ifdef __cplusplus

@@ -24,7 +24,7 @@ SYMBOLS = [
     "ipx_reserve", "ipx_push_batch", "ipx_finalize", "ipx_clear", "ipx_last_error",
     "ipx_finalize_shard", "ipx_copy", "ipx_records_pending", "ipx_records_sample",
     "ipx_records_partition", "ipx_records_adopt", "ipx_records_export", "ipx_last_timing", "ipx_profile",
-    "ipx_profile_read",
+    "ipx_profile_only", "ipx_profile_read",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     lib.ipx_records_export.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ipx_profile.argtypes = [vp, C.c_int]
+    lib.ipx_profile_only.argtypes = [vp, C.c_char_p]
     lib.ipx_profile_read.argtypes = [vp, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]
     for name in SYMBOLS:
         getattr(lib, name)

@@ -44,11 +44,20 @@ struct Arena {
 // event-pair profiler: a timeline of marks on the handle's stream
 struct Profiler {
     bool on = false;
+    int only = 0;                  // > 0: time the launches of this kernel class alone (an event before, one after)
     std::vector<hipEvent_t> pool;
     std::vector<int> ids;          // id of mark k (interval k-1 -> k is charged to ids[k])
     double total_ms[IPXK_COUNT] = {};
     uint64_t launches[IPXK_COUNT] = {};
     void mark(hipStream_t s, int id) {
+        if (only && id != only && id != IPXK_BEGIN) return;
+        if (only && id == IPXK_BEGIN) return;          // stage starts: the interval opens at pre()
+        record(s, id);
+    }
+    void pre(hipStream_t s, int id) {
+        if (only && id == only) record(s, IPXK_BEGIN);
+    }
+    void record(hipStream_t s, int id) {
         if (ids.size() == pool.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
@@ -78,6 +87,9 @@ struct Profiler {
 static thread_local Profiler *g_prof = nullptr;
 void ipx_prof_mark(hipStream_t s, int id) {
     if (g_prof && g_prof->on) g_prof->mark(s, id);
+}
+void ipx_prof_pre(hipStream_t s, int id) {
+    if (g_prof && g_prof->on) g_prof->pre(s, id);
 }
 struct ProfScope {
     explicit ProfScope(Profiler *p) { g_prof = p; }
@@ -856,8 +868,22 @@ static const char *const kKernelNames[IPXK_COUNT] = {
 int ipx_profile(ipx_handle *h, int enable) {
     if (!h) return IPX_EINVAL;
     h->prof.on = enable != 0;
+    h->prof.only = 0;
     h->prof.reset();
     return IPX_OK;
+}
+
+int ipx_profile_only(ipx_handle *h, const char *kernel) {
+    if (!h || !kernel) return IPX_EINVAL;
+    for (int i = 1; i < IPXK_COUNT; ++i) {
+        if (strcmp(kernel, kKernelNames[i]) != 0) continue;
+        if (i != IPXK_SCAN && i != IPXK_SORT_SCATTER && i != IPXK_PHASE_B) break;     // the bracketed classes
+        h->prof.on = true;
+        h->prof.only = i;
+        h->prof.reset();
+        return IPX_OK;
+    }
+    return fail(h, IPX_EINVAL, "ipx_profile_only: %s is not one of k_scan, k_scatter, k_reduce%ld", kernel, 0);
 }
 
 int ipx_profile_read(const ipx_handle *h, ipx_kernel_stat *out, uint32_t cap, uint32_t *n) {

@@ -192,6 +192,8 @@ enum IpxKernelId {
     IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_RANK_SORT, IPXK_COUNT
 };
 void ipx_prof_mark(hipStream_t s, int id);
+// before a launch of class id: opens the interval when that class alone is being timed (ipx_profile_only)
+void ipx_prof_pre(hipStream_t s, int id);
 
 // ---- launchers implemented in the kernel translation units -------------------
 // ipx_scan.hip

@@ -666,6 +666,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     // A record can fail the filter only against a motif and under "canon" (splice_juncs.cc:52-61)
     const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
     if (!filter_active) {
+        ipx_prof_pre(s, IPXK_PHASE_B);
         hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
                            rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
         ipx_prof_mark(s, IPXK_PHASE_B);

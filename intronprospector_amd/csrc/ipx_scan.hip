@@ -1025,6 +1025,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
     if (blocks > 256ull * 16) blocks = 256ull * 16;
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
+    ipx_prof_pre(s, IPXK_SCAN);
     hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
     // stripes pay once many blocks queue on the record counter
     static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();

@@ -364,6 +364,7 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_HIST);
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);
+        ipx_prof_pre(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);
         if (bytes && has_next)
             hipLaunchKernelGGL(k_scatter<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d, next_d,
                                hist, bin_total, n_tiles);

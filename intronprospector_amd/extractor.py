@@ -167,6 +167,10 @@ class JunctionsExtractor:
         """Switch per-kernel HIP-event timing on/off (resets the sums)."""
         self._check(self.lib.ipx_profile(self.h, int(enable)))
 
+    def profile_only(self, kernel):
+        """Time the launches of one kernel class ("k_scan", "k_scatter", "k_reduce") and nothing else."""
+        self._check(self.lib.ipx_profile_only(self.h, kernel.encode()))
+
     def profile_read(self):
         """-> {kernel name: (launches, total_ms)} since profile(True)."""
         arr = (L.KernelStat * 32)()

@@ -8,8 +8,8 @@
 //       writes PREFIX.juncs.bed, PREFIX.introns.bed, PREFIX.introns.bed6, PREFIX.introns.tsv with
 //       the output scheduling of src/intronProspector.cc:330-351
 //   ipx_host_check make-bam N OUT.bam
-//       N synthetic 100 bp spliced alignments (aM nN bM, sequence, qualities, NH/XS tags) as a BAM
-//       file, to time the decoder on
+//       N synthetic 100 bp spliced alignments (aM nN bM over 200 000 junction sites in coordinate order,
+//       sequence, qualities, NH/XS tags) as a BAM file, to time the decoder and the command line on
 //   ipx_host_check copy-aln IN OUT [XS|TS +|-]...
 //       pass-through writer: every record of IN to OUT in IN's container (SAM text / BAM), the given
 //       strand tags set on every record the way update_strand_tag does
@@ -126,8 +126,10 @@ static int make_bam(uint64_t n, const char *path) {
     for (uint64_t i = 0; i < n; ++i) {
         char name[32];
         const int ln = snprintf(name, sizeof name, "read%llu", (unsigned long long)i) + 1;
-        const uint32_t a = 10 + (uint32_t)(next() % 80), ilen = 70 + (uint32_t)(next() % 20000), b = 100 - a;
-        const uint32_t pos = (uint32_t)(i * 18 % 190000000);
+        // 200 000 junction sites, visited in coordinate order; a site's intron length is a function of the site
+        const uint64_t n_sites = 200000, site = i * n_sites / (n ? n : 1);
+        const uint32_t a = 10 + (uint32_t)(next() % 80), ilen = 70 + (uint32_t)((site * 2654435761ull) % 20000), b = 100 - a;
+        const uint32_t pos = (uint32_t)(site * 900 + 1000 - a);
         std::vector<uint8_t> r;
         put32(r, 0); put32(r, pos);
         r.push_back((uint8_t)ln); r.push_back(60); put16(r, 4681);

@@ -133,6 +133,11 @@ static inline bool ipx_window_is_first(const uint32_t vary[3], uint32_t max_bits
     return true;
 }
 #ifdef __HIPCC__
+// Lane mask of a predicate.  HIP's __ballot(int) first materialises the predicate as 0/1 in a vector
+// register and compares it again (two vector instructions per ballot); the builtin takes the condition's
+// lane mask as it is.
+__device__ __forceinline__ uint64_t ipx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // bits [lo, lo+w) of the 96-bit key (w <= 8)
 __device__ __forceinline__ uint32_t ipx_key_bits(const uint4 &it, uint32_t lo, uint32_t w) {
     const uint32_t word = lo >> 5, sh = lo & 31u;

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void k_count_heads(const uint4 *__restrict__ i
 #pragma unroll
     for (uint32_t r = 0; r < ROUNDS; ++r) {
         const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
-        cj += (uint32_t)__popcll(__ballot(h.head_j));
-        cb += (uint32_t)__popcll(__ballot(h.head_b));
+        cj += (uint32_t)__popcll(ipx_ballot(h.head_j));
+        cb += (uint32_t)__popcll(ipx_ballot(h.head_b));
     }
     if (lane == 0) { chunk_j[chunk] = cj; chunk_b[chunk] = cb; }
 }
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
 #pragma unroll
     for (uint32_t r = 0; r < ROUNDS; ++r) {
         const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
-        const uint64_t mj = __ballot(h.head_j), mb = __ballot(h.head_b);
+        const uint64_t mj = ipx_ballot(h.head_j), mb = ipx_ballot(h.head_b);
         const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
         const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
         if (h.head_b) {
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
     for (uint32_t r = 0; r < ROUNDS; ++r) {
         const uint64_t i = base + r * 64 + lane;
         const Heads h = load_heads(items, i, n, lane);
-        const uint64_t ok_mask = __ballot(h.ok);
+        const uint64_t ok_mask = ipx_ballot(h.ok);
         if (!ok_mask) break;
-        const uint64_t mj = __ballot(h.head_j), mb = __ballot(h.head_b);
+        const uint64_t mj = ipx_ballot(h.head_j), mb = ipx_ballot(h.head_b);
         const uint32_t jid = nj + (uint32_t)__popcll(mj & lane_le) - 1;
         const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
         nj += (uint32_t)__popcll(mj);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
             const bool runs_on = (last_j == 63) && ((ok_mask >> 63) & 1ull);   // may continue in the next round
             const bool began_here = (lane == 0 && cont0) ? here0 : true;
             if (is_head && !runs_on) flush_junction<MODE>(began_here, jid, v, first, creator, counts, amin, amax);
-            const uint64_t carry_mask = __ballot(is_head && runs_on);
+            const uint64_t carry_mask = ipx_ballot(is_head && runs_on);
             if (carry_mask) {
                 const int src = __ffsll((unsigned long long)carry_mask) - 1;
                 cj = bcast_acc(v, src);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
                 if (began_here) bin_count[bid] = s_bin;
                 else if (s_bin) atomicAdd(&bin_count[bid], s_bin);
             }
-            const uint64_t carry_mask = __ballot(is_head && runs_on);
+            const uint64_t carry_mask = ipx_ballot(is_head && runs_on);
             if (carry_mask) {
                 const int src = __ffsll((unsigned long long)carry_mask) - 1;
                 cb_cnt = __shfl(s_bin, src);

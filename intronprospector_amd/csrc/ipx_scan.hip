@@ -412,10 +412,10 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
         const bool last = run && left == 1;                             // finish() :278-282 follows this op
 
         // ---- store waiting snapshots: when one is about to be overwritten or orphaned, or enough wait
-        const unsigned long long pm = __ballot(pending);
-        if (pm && (__ballot(pending && (trig || last || !active)) || __popcll(pm) >= (int)LONG_DRAIN)) {
+        const unsigned long long pm = ipx_ballot(pending);
+        if (pm && (ipx_ballot(pending && (trig || last || !active)) || __popcll(pm) >= (int)LONG_DRAIN)) {
             const bool pass = pending && snap_ok();
-            const unsigned long long em = __ballot(pass);
+            const unsigned long long em = ipx_ballot(pass);
             if (pass) {
                 const uint32_t slot = pool_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
         const bool adv = c_m || c_n || (c_id && op == 2);               // M = X N D move along the reference
         const bool carry = adv && tpn < tp;
         const bool bad = run && cls == 0;
-        if (__ballot(carry || bad)) {                                    // rare, wave-uniform
+        if (ipx_ballot(carry || bad)) {                                    // rare, wave-uniform
             if (carry) {                                                 // offsets leave 32 bits: 64-bit re-run
                 if (trig) pending = false;                               // this op's junction comes from the re-run too
                 redo = true;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
 
     for (;;) {
         // ---- 64-bit re-run of alignments whose offsets left 32 bits (after their snapshot is stored)
-        if (__ballot(redo && !pending)) {
+        if (ipx_ballot(redo && !pending)) {
             if (redo && !pending) {
                 ReadCtx c;
                 c.pos = (int32_t)pos32; c.flag = 0; c.nhc = 0; c.rank = rank;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
             }
         }
         // ---- hand out alignments
-        const unsigned long long idle = __ballot(!active && !warm && !pending && !redo);
+        const unsigned long long idle = ipx_ballot(!active && !warm && !pending && !redo);
         if (idle) {
             if (next >= range_end) {
                 if (idle == ~0ull) break;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
             // QC, pack and store the waiting snapshots of the whole wave
             auto drain = [&]() {
                 const bool pass = pending && snap_ok();
-                const unsigned long long em = __ballot(pass);
+                const unsigned long long em = ipx_ballot(pass);
                 if (em) {
                     uint32_t base = 0;
                     if (lane == (uint32_t)(__ffsll((unsigned long long)em) - 1)) base = atomicAdd(&pool_n, (uint32_t)__popcll(em));
@@ -763,14 +763,14 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
                 const bool over = c_id && indel2 > p.max_anchor_indel_size;
                 const bool trig = in_r && (c_n || c_sh || over);
                 const bool last = run && left == 1;
-                if (__ballot(pending && (trig || last))) drain();
+                if (ipx_ballot(pending && (trig || last))) drain();
                 s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
                 s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
                 pending = pending || trig;
                 const uint32_t tpn = tp + len;
                 const bool adv = c_m || c_n || (c_id && op == 2);
                 const bool bad = run && cls == 0;
-                if (__ballot(bad)) {
+                if (ipx_ballot(bad)) {
                     if (bad) {                                              // :312-313: the exception ends the read
                         const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
                         const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
@@ -807,15 +807,15 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
             };
             step(wa.x);
             step(wa.y);
-            if (__ballot(active)) step(wa.z);
-            if (__ballot(active)) step(wa.w);
-            if (__ballot(active)) step(wb.x);
-            if (__ballot(active)) step(wb.y);
-            if (__ballot(active)) step(wb.z);
-            if (__ballot(active)) step(wb.w);
-            if (__ballot(pending)) drain();
+            if (ipx_ballot(active)) step(wa.z);
+            if (ipx_ballot(active)) step(wa.w);
+            if (ipx_ballot(active)) step(wb.x);
+            if (ipx_ballot(active)) step(wb.y);
+            if (ipx_ballot(active)) step(wb.z);
+            if (ipx_ballot(active)) step(wb.w);
+            if (ipx_ballot(pending)) drain();
             // CIGARs of more than 8 ops in a short-CIGAR batch: the op-by-op walk
-            if (__ballot(nc > 8)) {
+            if (ipx_ballot(nc > 8)) {
                 if (nc > 8) (void)run_read<2>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err, &pool);
             }
         }
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256) void k_close_find(Counters *counters, uint64_t
         const uint64_t i = ((chunk / IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS) | (pos & ((1u << IPX_STRIPE_CHUNK_BITS) - 1));
         const bool taken = pos < st.extent && i < st.count[k];
         const bool hole = pos < st.n && !taken, tail = pos >= st.n && taken;
-        const unsigned long long hm = __ballot(hole), tm = __ballot(tail);
+        const unsigned long long hm = ipx_ballot(hole), tm = ipx_ballot(tail);
         if (hm) {
             unsigned long long at = 0;
             if (lane == 0) at = atomicAdd(n_holes, (unsigned long long)__popcll(hm));

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
                     consumed = true;
                 }
             }
-            const uint64_t not_consumed = ~__ballot(consumed);
+            const uint64_t not_consumed = ~ipx_ballot(consumed);
             const uint32_t n_in = not_consumed ? (uint32_t)(__ffsll((unsigned long long)not_consumed) - 1) : 64u;
             next_rid += n_in;
             next_off = next_rid < rb ? (uint64_t)a.off[next_rid] : ~0ull;
@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
         __builtin_amdgcn_wave_barrier();
         const uint32_t hv = heads_here ? head_s[lane] : 0u;
         const bool is_head = valid && hv != 0;
-        const uint64_t mH = __ballot(is_head);
+        const uint64_t mH = ipx_ballot(is_head);
         const int h_k = top_bit(mH & le_mask(lane));                      // my alignment's head lane, -1: carried
         const uint32_t seg_lo = h_k >= 0 ? (uint32_t)h_k : 0u;
         const uint64_t seg = le_mask(lane) & ~lt_mask(seg_lo);            // lanes of my alignment up to me
@@ -198,21 +198,21 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
                    op_clip = (op == 4) | (op == 5);
         const bool op_bad = valid && live && !(op_a | op_n | op_id | op_clip);
         // the exception ends the alignment: nothing after the first bad op counts (junctions_extractor.cc:312-313)
-        const uint64_t m_bad = __ballot(op_bad);
+        const uint64_t m_bad = ipx_ballot(op_bad);
         const bool dead = (fresh ? 0u : c.dead) || (m_bad & seg_x) != 0;
         const bool act = valid && live && !dead && !op_bad;
 
         // run of insertions/deletions since the last A/N (S/H do not reset it, :153-158, :227, :252)
         const uint32_t g_len = (act && op_id) ? len : 0u;
         const uint32_t gI = wave_incl_scan(g_len, lane);
-        const uint64_t m_reset = __ballot(valid && (op_a | op_n)) | mH;          // A, N or a new alignment reset cur
+        const uint64_t m_reset = ipx_ballot(valid && (op_a | op_n)) | mH;          // A, N or a new alignment reset cur
         const int rs_k = top_bit(m_reset & seg);                                  // last reset at or before me
         // value BEFORE the resetting lane's own contribution (a head that is itself an I/D keeps its length)
         const uint32_t g_at_reset = __shfl(gI - g_len, rs_k >= 0 ? rs_k : 0);
         const uint32_t cur = (rs_k >= 0) ? gI - g_at_reset : c.cur + gI;          // no reset in sight: carried run
         const bool tok_b = act && (op_clip | (op_id && cur > p.max_anchor_indel_size));
         const bool tok_a = act && op_a, tok_n = act && op_n;
-        const uint64_t mA = __ballot(tok_a), mN = __ballot(tok_n), mB = __ballot(tok_b);
+        const uint64_t mA = ipx_ballot(tok_a), mN = ipx_ballot(tok_n), mB = ipx_ballot(tok_b);
 
         // ---- state before every op ---------------------------------------------------------------
         const int b_k = top_bit(mB & seg_x);                                       // last break before me
@@ -247,10 +247,10 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
             const uint32_t got = __shfl(v, j >= 0 ? j : 0);
             return j >= 0 ? got : (fresh ? 0u : carry);
         };
-        const uint64_t m_toLF = __ballot(tok_a && sb == S_LIMBO);
-        const uint64_t m_toRT = __ballot(tok_a && sb == S_INTRON);
-        const uint64_t m_shift = __ballot(tok_n && sb == S_RIGHT);
-        const uint64_t m_toIN = __ballot(tok_n && (sb == S_LEFT || sb == S_RIGHT));
+        const uint64_t m_toLF = ipx_ballot(tok_a && sb == S_LIMBO);
+        const uint64_t m_toRT = ipx_ballot(tok_a && sb == S_INTRON);
+        const uint64_t m_shift = ipx_ballot(tok_n && sb == S_RIGHT);
+        const uint64_t m_toIN = ipx_ballot(tok_n && (sb == S_LEFT || sb == S_RIGHT));
         const uint32_t toLF_tp = last_at(m_toLF, true, tp, c.toLF_tp), toLF_xl = last_at(m_toLF, true, xl, c.toLF_xl);
         const uint32_t toRT_tp = last_at(m_toRT, true, tp, c.toRT_tp), toRT_xr = last_at(m_toRT, true, xr, c.toRT_xr);
         const uint32_t lastA_end = last_at(mA, true, tp + len, c.lastA_end);
@@ -289,7 +289,7 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
             pass = !rejected && ilen >= (int64_t)p.min_intron_length && ilen <= (int64_t)p.max_intron_length &&
                    left >= (int64_t)p.min_anchor_length && right >= (int64_t)p.min_anchor_length;   // :392-397
         }
-        const uint64_t m_pass = __ballot(pass);
+        const uint64_t m_pass = ipx_ballot(pass);
         const uint32_t ord = (fresh ? 0u : c.ord) + (uint32_t)__popcll(m_pass & seg_x);
         if (op_bad && !dead) {
             const unsigned long long e = ((a.base_read_index + rid) << IPX_ORD_SHIFT_READ) |
@@ -352,7 +352,7 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
         }
 
         // ---- carry: everything as of after the chunk's last valid word ---------------------------
-        const uint64_t m_valid = __ballot(valid);
+        const uint64_t m_valid = ipx_ballot(valid);
         const int L = top_bit(m_valid);                    // last valid lane (>= 0)
 #define RL(x) ((uint32_t)__builtin_amdgcn_readlane((int)(x), L))
         c.rid = ((uint64_t)RL((uint32_t)(rid >> 32)) << 32) | RL((uint32_t)rid);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_scan_ops(OpsArgs a) {
         __syncthreads();
     }
     if (lane == 0 && err != IPX_ERRW_NONE) atomicMin(&a.counters->err_word, err);
-    if (__ballot(layout_bad) && lane == 0) atomicOr(&a.counters->pad[0], 1u);
+    if (ipx_ballot(layout_bad) && lane == 0) atomicOr(&a.counters->pad[0], 1u);
     // OR / AND of the stored keys
     uint32_t v[6];
 #pragma unroll

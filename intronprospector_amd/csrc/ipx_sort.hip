@@ -65,9 +65,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
                     // are one value -> one LDS add instead of 8 (512) on a single, contended bin
                     const uint32_t b0 = v[g].x & 0xffu;
                     const bool uni = (v[g].x == b0 * 0x01010101u) && (v[g].y == v[g].x);
-                    const uint64_t act = __ballot(1);
+                    const uint64_t act = ipx_ballot(1);
                     const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
-                    if (__ballot(uni && b0 == first) == act) {
+                    if (ipx_ballot(uni && b0 == first) == act) {
                         if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
                             atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
                     } else if (uni) {
@@ -185,10 +185,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restric
         const uint32_t dig = ok ? digit_of(it[r], d) : 0xffffffffu;
         dg[r] = dig;
         // lanes with the same digit (invalid lanes match nobody valid)
-        uint64_t peers = __ballot(ok);
+        uint64_t peers = ipx_ballot(ok);
 #pragma unroll
         for (uint32_t bit = 0; bit < 8; ++bit) {
-            const uint64_t bm = __ballot((dig >> bit) & 1u);
+            const uint64_t bm = ipx_ballot((dig >> bit) & 1u);
             peers &= ((dig >> bit) & 1u) ? bm : ~bm;
         }
         uint32_t before = 0;

@@ -150,7 +150,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restric
     __shared__ uint32_t wsum[4], wsum2[4];
 
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
     const uint32_t valid = (uint32_t)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
 
@@ -192,12 +191,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restric
             peers &= ((dig >> bit) & 1u) ? bm : ~bm;
         }
         uint32_t before = 0;
+        // equal-digit lanes below this one: v_mbcnt counts the mask bits below the lane in two instructions
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
         if (ok) {
             before = cnt[wave][dig];
-            rk[r] = before + (uint32_t)__popcll(peers & lane_lt);
+            rk[r] = before + below;
         }
         __builtin_amdgcn_wave_barrier();
-        if (ok && (peers & lane_lt) == 0) cnt[wave][dig] = before + (uint32_t)__popcll(peers);
+        if (ok && below == 0) cnt[wave][dig] = before + (uint32_t)__popcll(peers);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();

@@ -368,6 +368,32 @@ def test_striped_append_with_uneven_stripes_and_capacity_retry():
     o.close()
 
 
+def test_short_cigar_tiles_that_overflow_the_record_pool():
+    """Three junctions per alignment: a tile of 512 alignments emits 1536 records, more than the 704 the
+    LDS pool of k_scan_short holds -> the count / reserve / re-run fallback, here together with the
+    striped append (>= 64 blocks) and with a tail of ordinary alignments in the same launch."""
+    from intronprospector_amd import synth
+    rng = np.random.default_rng(95)
+    n = 40_000
+    pos = np.sort(rng.integers(1000, 3_000_000, n)).astype(np.int32)
+    a = rng.integers(9, 30, (n, 4)).astype(np.uint32)
+    il = rng.choice(np.array([80, 150, 400, 2500], np.uint32), (n, 3))
+    words = np.empty((n, 7), np.uint32)
+    words[:, 0::2] = a << 4                                  # M
+    words[:, 1::2] = (il << 4) | 3                           # N
+    dense = {"tid": (rng.integers(0, 2, n)).astype(np.int32), "pos": pos, "flag": np.zeros(n, np.uint16),
+             "xs": np.zeros(n, np.uint8), "nh": np.ones(n, np.uint8),
+             "cigar_off": (np.arange(n, dtype=np.uint32) * 7), "n_cigar": np.full(n, 7, np.uint32),
+             "cigar": words.reshape(-1)}
+    usual, names, _ = synth.short_reads(30_000, seed=96, n_targets=2, target_len=4_000_000, n_sites=500)
+    batch = synth.concat_batches([dense, usual])
+    dev, ora, err = _run_both(batch, names, {})
+    assert err is None and int(ora["counts"].sum()) > 3 * n
+    helpers.compare_tables(dev, ora)
+    dev2, _, _ = _run_both(batch, names, {}, n_push=3)
+    helpers.compare_tables(dev2, ora)
+
+
 def test_ijunc_by_radix_sort_when_the_bitmap_does_not_apply(monkeypatch):
     """ijunc normally comes from a bitmap over the squeezed creation-order keys; IPX_RANK=sort forces
     the radix sort that serves keys with more than 28 varying bits or more than four runs of them."""

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
         const uint32_t last_j = seg_last_lane(heads_j, lane);
         if (MODE != 2) {
             v.m1 = seg_reduce(v.m1, lane, last_j, MinU64());
-            v.m2 = seg_reduce(v.m2, lane, last_j, MinU64());
+            v.m2 = (MODE == 0) ? v.m1 : seg_reduce(v.m2, lane, last_j, MinU64());   // MODE 0: first == creator
         }
         if (MODE != 1) {
             uint32_t cpk = v.c0 | (v.c1 << 8) | (v.c2 << 16);          // <= 64 per field and round

@@ -654,10 +654,19 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
     __shared__ unsigned long long tile_slot;
     __shared__ uint4 pool_item[POOL], pool_pay[POOL];
     __shared__ uint32_t pool_n;
+    __shared__ uint16_t cx_list[256 * RPT];       // tile-local indices of the alignments that need the walk
+    __shared__ uint32_t cx_n;
     const Pool pool{pool_item, pool_pay, &pool_n, POOL};
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + 256ull * RPT - 1) / (256ull * RPT);
     const uint32_t stripe = my_stripe(p);
+    // slots of the tile's pool for the lanes of `mask` (one LDS atomic per wave)
+    auto pool_slot = [&](unsigned long long mask) {
+        const int first = __ffsll(mask) - 1;
+        uint32_t base = 0;
+        if ((int)lane == first) base = atomicAdd(&pool_n, (uint32_t)__popcll(mask));
+        return __shfl(base, first) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    };
 
     auto load_ctx = [&](uint64_t i, ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
         c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = base_read_index + i;
@@ -695,14 +704,68 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         unsigned long long my_err = IPX_ERRW_NONE;
-        if (t == 0) pool_n = 0;
+        if (t == 0) { pool_n = 0; cx_n = 0; }
         __syncthreads();
-#pragma unroll 1
+        // Phase 1, every alignment of the tile: the plain spliced read "aM nN bM" (two thirds of short-read
+        // data) has a closed form -- one junction, anchors a and b, no counters.  Everything else is only
+        // LISTED here and walked in phase 2 by as few waves as it fills: a wave runs the eight-step walk
+        // for all its lanes or for none, so packing the alignments that need it saves most of the walks.
+        // (the loads of all RPT rounds first: a round's two dependent round trips overlap the other's)
+        ReadCtx c_r[RPT];
+        uint32_t nc_r[RPT], off_r[RPT];
+        uint4 w3_r[RPT];
+#pragma unroll
+        for (uint32_t r = 0; r < RPT; ++r)
+            load_ctx(tile * (256ull * RPT) + (uint64_t)r * 256 + t, c_r[r], nc_r[r], off_r[r], my_err);
+#pragma unroll
+        for (uint32_t r = 0; r < RPT; ++r)
+            w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
+#pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
-            const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+            const ReadCtx &c = c_r[r];
+            const uint32_t nc = nc_r[r];
+            const uint4 w3 = w3_r[r];
+            const bool plain = nc == 3 && (w3.x & 0xfu) == 0 && (w3.y & 0xfu) == 3 && (w3.z & 0xfu) == 0;
+            const bool walk_it = nc != 0 && !plain;
+            const unsigned long long wm = ipx_ballot(walk_it);
+            if (wm) {
+                const int first = __ffsll(wm) - 1;
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(&cx_n, (uint32_t)__popcll(wm));
+                base = __shfl(base, first);
+                if (walk_it) cx_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))] =
+                    (uint16_t)(r * 256 + t);
+            }
+            // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, finish(): one record (junctions_extractor.cc:208-254,278-282)
+            const uint32_t a = w3.x >> 4, nl = w3.y >> 4, b = w3.z >> 4;
+            const bool pass = plain && !c.read_rejected && nl >= p.min_intron_length && nl <= p.max_intron_length &&
+                              a >= p.min_anchor_length && b >= p.min_anchor_length;      // junction_qc :392-397
+            const unsigned long long em = ipx_ballot(pass);
+            if (em) {
+                const uint32_t slot = pool_slot(em);
+                if (pass && slot < POOL) {
+                    ReadCtx cc = c;
+                    cc.pos = 0;
+                    uint4 it, pay;
+                    const Rec rr{0, (int64_t)a, (int64_t)(a + nl), (int64_t)(a + nl + b), 0, 0, 0, 0};
+                    pack_record_rel(p, cc, rr, (uint32_t)c.pos, 0u, it, pay);
+                    pool_item[slot] = it;
+                    pool_pay[slot] = pay;
+                }
+            }
+        }
+        __syncthreads();
+        // Phase 2: the listed alignments, 64 per wave
+        const uint32_t n_walk = cx_n;
+#pragma unroll 1
+        for (uint32_t k0 = wave * 64; k0 < n_walk; k0 += 256) {
+            const bool mine = k0 + lane < n_walk;
+            const uint64_t i = tile * (256ull * RPT) + (mine ? cx_list[k0 + lane] : 0u);
             ReadCtx c;
-            uint32_t nc, off;
-            load_ctx(i, c, nc, off, my_err);
+            uint32_t nc = 0, off = 0;
+            unsigned long long seen = IPX_ERRW_NONE;         // gate errors were reported in phase 1
+            load_ctx(i, c, nc, off, seen);
+            if (!mine) nc = 0;
             const bool small = nc != 0 && nc <= 8;
             // both chunks always (a lane without a short CIGAR reads the array's first words)
             const uint4 wa = load_cigar4(cigar, tail, n_words, small ? (uint64_t)off : 0ull);
@@ -729,12 +792,8 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
                 const bool pass = pending && snap_ok();
                 const unsigned long long em = ipx_ballot(pass);
                 if (em) {
-                    uint32_t base = 0;
-                    if (lane == (uint32_t)(__ffsll((unsigned long long)em) - 1)) base = atomicAdd(&pool_n, (uint32_t)__popcll(em));
-                    base = __shfl(base, __ffsll((unsigned long long)em) - 1);
+                    const uint32_t slot = pool_slot(em);
                     if (pass) {
-                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
-                                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
                         if (slot < POOL) {
                             ReadCtx cc = c;
                             cc.pos = 0;

@@ -632,8 +632,8 @@ __global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uin
 // out of 32-bit offsets.  A finished junction is snapshotted; snapshots are QC'd, packed and stored for
 // all lanes of the wave at once -- when a lane is about to finish a second junction, and at the end.
 // Alignments with more than 8 ops in such a batch (a few per cent at most) take run_read<2>.
-template <uint32_t RPT, uint32_t POOL>
-__global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
+template <uint32_t RPT, uint32_t POOL, uint32_t BT>
+__global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                                     const int32_t *__restrict__ a_tid,
                                                     const int32_t *__restrict__ a_pos,
                                                     const uint16_t *__restrict__ a_flag,
@@ -647,18 +647,19 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
                                                     uint4 *__restrict__ items, uint4 *__restrict__ pays,
                                                     uint8_t *__restrict__ digs,
                                                     uint64_t capacity, Counters *counters) {
-    __shared__ uint32_t wsum[RPT][4];
-    __shared__ uint32_t kb_s[4][6];
+    constexpr uint32_t NW = BT / 64;                 // waves per block
+    __shared__ uint32_t wsum[RPT][NW];
+    __shared__ uint32_t kb_s[NW][6];
     KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
-    __shared__ uint32_t cnt_s[RPT][256], base_s[RPT][256];
+    __shared__ uint32_t cnt_s[RPT][BT], base_s[RPT][BT];
     __shared__ unsigned long long tile_slot;
     __shared__ uint4 pool_item[POOL], pool_pay[POOL];
     __shared__ uint32_t pool_n;
-    __shared__ uint16_t cx_list[256 * RPT];       // tile-local indices of the alignments that need the walk
+    __shared__ uint16_t cx_list[BT * RPT];       // tile-local indices of the alignments that need the walk
     __shared__ uint32_t cx_n;
     const Pool pool{pool_item, pool_pay, &pool_n, POOL};
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t n_tiles = (n + 256ull * RPT - 1) / (256ull * RPT);
+    const uint64_t n_tiles = (n + (uint64_t)BT * RPT - 1) / ((uint64_t)BT * RPT);
     const uint32_t stripe = my_stripe(p);
     // slots of the tile's pool for the lanes of `mask` (one LDS atomic per wave)
     auto pool_slot = [&](unsigned long long mask) {
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
         uint4 w3_r[RPT];
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r)
-            load_ctx(tile * (256ull * RPT) + (uint64_t)r * 256 + t, c_r[r], nc_r[r], off_r[r], my_err);
+            load_ctx(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, c_r[r], nc_r[r], off_r[r], my_err);
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r)
             w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
                 if ((int)lane == first) base = atomicAdd(&cx_n, (uint32_t)__popcll(wm));
                 base = __shfl(base, first);
                 if (walk_it) cx_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))] =
-                    (uint16_t)(r * 256 + t);
+                    (uint16_t)(r * BT + t);
             }
             // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, finish(): one record (junctions_extractor.cc:208-254,278-282)
             const uint32_t a = w3.x >> 4, nl = w3.y >> 4, b = w3.z >> 4;
@@ -758,9 +759,9 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
         // Phase 2: the listed alignments, 64 per wave
         const uint32_t n_walk = cx_n;
 #pragma unroll 1
-        for (uint32_t k0 = wave * 64; k0 < n_walk; k0 += 256) {
+        for (uint32_t k0 = wave * 64; k0 < n_walk; k0 += BT) {
             const bool mine = k0 + lane < n_walk;
-            const uint64_t i = tile * (256ull * RPT) + (mine ? cx_list[k0 + lane] : 0u);
+            const uint64_t i = tile * ((uint64_t)BT * RPT) + (mine ? cx_list[k0 + lane] : 0u);
             ReadCtx c;
             uint32_t nc = 0, off = 0;
             unsigned long long seen = IPX_ERRW_NONE;         // gate errors were reported in phase 1
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
             if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;
-            for (uint32_t k = t; k < total; k += 256) {
+            for (uint32_t k = t; k < total; k += BT) {
                 const uint64_t idx = append_index(p, stripe, slot + k);
                 if (idx < capacity) {
                     uint4 it = pool_item[k];
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
             // the pool overflowed: count, reserve, re-run (k_scan's scheme); errors were collected above
 #pragma unroll 1
             for (uint32_t r = 0; r < RPT; ++r) {
-                const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+                const uint64_t i = tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t;
                 unsigned long long dummy = IPX_ERRW_NONE;
                 ReadCtx c;
                 uint32_t nc, off;
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
 #pragma unroll 1
             for (uint32_t r = 0; r < RPT; ++r) {
                 uint32_t before = tile_total;
-                for (uint32_t w = 0; w < 4; ++w) {
+                for (uint32_t w = 0; w < NW; ++w) {
                     const uint32_t sw = wsum[r][w];
                     if (w < wave) before += sw;
                     tile_total += sw;
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
 #pragma unroll 1
             for (uint32_t r = 0; r < RPT; ++r) {
                 if (cnt_s[r][t]) {
-                    const uint64_t i = tile * (256ull * RPT) + (uint64_t)r * 256 + t;
+                    const uint64_t i = tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t;
                     unsigned long long dummy = IPX_ERRW_NONE;
                     ReadCtx c;
                     uint32_t nc, off;
@@ -963,12 +964,11 @@ __global__ __launch_bounds__(256) void k_scan_short(ScanParams p, uint64_t n, ui
     }
     __syncthreads();
     if (t < 6) {
-        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        uint32_t o = 0, a = ~0u;
+        for (uint32_t w = 0; w < NW; ++w) { o |= kb_s[w][t]; a &= kb_s[w][t]; }
         if (t < 3) {
-            const uint32_t o = x0 | x1 | x2 | x3;
             if (o) atomicOr(&counters->key_or[t], o);
         } else {
-            const uint32_t a = x0 & x1 & x2 & x3;
             if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
         }
     }
@@ -1080,9 +1080,13 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     if (b.n_alignments == 0) return hipSuccess;
     // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
     const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;      // (the long kernel needs >= 8 words)
-    const uint64_t per_tile = short_reads ? 512 : 256;
+    // short CIGARs: blocks of 128 threads, 2 alignments per thread: a tile's steps (loads, walk, one
+    // reservation, copy-out) are a chain of latencies, and eight small tiles in flight per CU hide it
+    // better than four large ones
+    static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 256 ? 256 : 128); }();
+    const uint64_t per_tile = short_reads ? 2ull * short_bt : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
-    if (blocks > 256ull * 16) blocks = 256ull * 16;
+    if (blocks > 256ull * 32) blocks = 256ull * 32;
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     ipx_prof_pre(s, IPXK_SCAN);
     hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
@@ -1090,8 +1094,12 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
     p.base = n_records_before;
     p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
-    if (short_reads)
-        hipLaunchKernelGGL((k_scan_short<2, 704>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+    if (short_reads && short_bt == 256)
+        hipLaunchKernelGGL((k_scan_short<2, 704, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
+                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+    else if (short_reads)
+        hipLaunchKernelGGL((k_scan_short<2, 384, 128>), dim3((uint32_t)blocks), dim3(128), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
     else {

@@ -1082,11 +1082,21 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;      // (the long kernel needs >= 8 words)
     // short CIGARs: blocks of 128 threads, 2 alignments per thread: a tile's steps (loads, walk, one
     // reservation, copy-out) are a chain of latencies, and eight small tiles in flight per CU hide it
-    // better than four large ones
-    static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 256 ? 256 : 128); }();
+    // better than four large ones.  The grid is what is resident at once (8 such blocks per CU by
+    // registers), every block loops over tiles: fewer blocks leave CUs idle, more add a ragged last
+    // round and more end-of-block atomics on the key masks (measured: 2048 blocks 0.32 ms, 2560 0.42,
+    // 8192 0.36, 16384 0.48 on 10 M alignments).
+    static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 256 ? 256 : v == 64 ? 64 : 128); }();
+    static const uint32_t n_cus = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return (uint32_t)cus;
+    }();
     const uint64_t per_tile = short_reads ? 2ull * short_bt : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
-    if (blocks > 256ull * 32) blocks = 256ull * 32;
+    static const uint64_t max_blocks = [] { const char *e = getenv("IPX_SCAN_BLOCKS"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
+    const uint64_t resident = max_blocks ? max_blocks : (uint64_t)n_cus * (1024u / short_bt);
+    if (blocks > resident) blocks = resident;
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     ipx_prof_pre(s, IPXK_SCAN);
     hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
@@ -1096,6 +1106,10 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
     if (short_reads && short_bt == 256)
         hipLaunchKernelGGL((k_scan_short<2, 704, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
+                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+    else if (short_reads && short_bt == 64)
+        hipLaunchKernelGGL((k_scan_short<2, 192, 64>), dim3((uint32_t)blocks), dim3(64), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
     else if (short_reads)

@@ -130,6 +130,81 @@ def test_cli_reads_standard_input(cli, golden, tmp_path):
         assert open(out, "rb").read() == exp, (src, piped)
 
 
+def _fuzz_sam(path, seed, n=4000, sorted_by_target=True, mapped_unmapped=False):
+    """SAM text with the odd cases of real files: unmapped reads, `*` CIGARs, `=`/`X`, clips, indels,
+    NH of every integer type and value, XS of type A and of other types, duplicate tags, long names."""
+    import random
+    rng = random.Random(seed)
+    names = ["chrB", "chrA", "chr10", "chr2"]
+    recs = []
+    for i in range(n):
+        t = rng.randrange(len(names))
+        pos = rng.randrange(1, 200000)
+        ops = []
+        for _ in range(rng.choice([1, 3, 3, 3, 5, 5, 7, 9])):
+            ops.append(rng.choice(["M", "M", "M", "N", "N", "I", "D", "=", "X", "S"]))
+        cig = "".join("%d%s" % (rng.choice([75, 80, 300, 4000]) if o == "N" else rng.randrange(1, 40), o) for o in ops)
+        flag = rng.choice([0, 16, 99, 147, 83, 163, 256, 272, 1024, 512, 2048, 4])
+        if rng.random() < 0.03:
+            cig = "*"
+        tags = []
+        r = rng.random()
+        if r < 0.5: tags.append("NH:i:%d" % rng.choice([0, 1, 1, 1, 2, 7, 300, 70000]))
+        elif r < 0.55: tags.append("NH:Z:2")
+        r = rng.random()
+        if r < 0.3: tags.append("XS:A:%s" % rng.choice("+-.?"))
+        elif r < 0.35: tags.append("XS:i:5")
+        if rng.random() < 0.1: tags.append("XS:A:+")                     # a second XS: the first one counts
+        if rng.random() < 0.2: tags.insert(0, "MD:Z:%d" % rng.randrange(100))
+        # (an unmapped-flagged read that still names a target and a spliced CIGAR makes the reference throw)
+        rname = names[t] if flag != 4 or (mapped_unmapped and i > n // 2 and rng.random() < 0.5) else "*"
+        recs.append((t if rname != "*" else 99, pos, "read_%d_%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t*\t*%s" % (
+            i, "x" * rng.choice([0, 0, 40]), flag, rname, pos if rname != "*" else 0, rng.randrange(61), cig,
+            "".join("\t" + x for x in tags))))
+    if sorted_by_target:
+        recs.sort(key=lambda r: (r[0], r[1]))
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.6\tSO:coordinate\n")
+        for nm in names:
+            f.write("@SQ\tSN:%s\tLN:1000000\n" % nm)
+        for r in recs:
+            f.write(r[2] + "\n")
+
+
+@pytest.mark.parametrize("opts", [
+    ["--min-confidence-score=0.0"],
+    ["--min-confidence-score=0.0", "--allow-anchor-indels", "--max-anchor-indel-size=5", "--min-anchor-length=3"],
+    ["--strandness=RF", "--excludes=multi", "--min-confidence-score=0.5"],
+    ["--unsorted", "--strandness=FR", "--min-intron-length=76", "--max-intron-length=3999"],
+])
+def test_cli_against_the_oracle_on_odd_sam_files(cli, oracle_cli, tmp_path, opts):
+    """The whole command line (SAM parsing included) against the oracle's, outputs byte for byte."""
+    sam = str(tmp_path / "odd.sam")
+    _fuzz_sam(sam, seed=len(" ".join(opts)), sorted_by_target="--unsorted" not in opts)
+    outs = {}
+    for who, exe in (("got", cli), ("exp", oracle_cli)):
+        o = {k: str(tmp_path / ("%s.%s" % (who, k))) for k in ("juncs.bed", "introns.bed", "introns.bed6", "introns.tsv", "trace.tsv")}
+        r = subprocess.run([exe] + opts + ["--junction-bed=" + o["juncs.bed"], "--intron-bed=" + o["introns.bed"],
+                                           "--intron-bed6=" + o["introns.bed6"], "--intron-calls=" + o["introns.tsv"],
+                                           "--debug-trace=" + o["trace.tsv"], sam],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        outs[who] = (r.returncode, r.stderr, {k: open(v, "rb").read() for k, v in o.items()})
+    assert outs["got"][0] == outs["exp"][0] == 0, (outs["got"][1], outs["exp"][1])
+    assert outs["got"][1] == outs["exp"][1]
+    for k in outs["exp"][2]:
+        assert outs["got"][2][k] == outs["exp"][2][k], k
+    assert outs["exp"][2]["trace.tsv"].count(b"\n") > 20
+    # get_read_category's logic_error (src/junctions_extractor.cc:73-74): same message, same exit status, and
+    # what the earlier targets had already written stays written
+    _fuzz_sam(sam, seed=7, sorted_by_target=True, mapped_unmapped=True)
+    res = []
+    for who, exe in (("got", cli), ("exp", oracle_cli)):
+        tsv = str(tmp_path / (who + ".err.tsv"))
+        r = subprocess.run([exe] + opts + ["--intron-calls=" + tsv, sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        res.append((r.returncode, r.stderr, open(tsv, "rb").read()))
+    assert res[0] == res[1] and res[0][0] == 1 and b"should never look at" in res[0][1]
+
+
 def test_cli_gzip_outputs(cli, golden, tmp_path):
     import gzip
     out = {s: str(tmp_path / ("b1." + s + ".gz")) for s in ("juncs.bed", "introns.bed", "introns.tsv")}

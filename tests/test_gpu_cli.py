@@ -194,6 +194,14 @@ def test_cli_against_the_oracle_on_odd_sam_files(cli, oracle_cli, tmp_path, opts
     for k in outs["exp"][2]:
         assert outs["got"][2][k] == outs["exp"][2][k], k
     assert outs["exp"][2]["trace.tsv"].count(b"\n") > 20
+    # the same alignments as BAM (every integer width for NH, non-A XS, `*` CIGARs, unplaced reads)
+    bam = str(tmp_path / "odd.bam")
+    bamio.sam_to_bam(sam, bam)
+    tsv = str(tmp_path / "bam.introns.tsv")
+    trace = str(tmp_path / "bam.trace.tsv")
+    subprocess.run([cli] + opts + ["--intron-calls=" + tsv, "--debug-trace=" + trace, bam], check=True)
+    assert open(tsv, "rb").read() == outs["exp"][2]["introns.tsv"]
+    assert open(trace, "rb").read() == outs["exp"][2]["trace.tsv"]
     # get_read_category's logic_error (src/junctions_extractor.cc:73-74): same message, same exit status, and
     # what the earlier targets had already written stays written
     _fuzz_sam(sam, seed=7, sorted_by_target=True, mapped_unmapped=True)

@@ -79,7 +79,21 @@ bool BgzfReader::read_block(Slot &s) {
 void BgzfReader::worker() {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) return;
+    if (inflateInit2(&zs, -15) != Z_OK) {           // no inflater: fail the next block instead of leaving the consumer waiting
+        std::unique_lock<std::mutex> lk(m_);
+        if (next_claim_ < end_seq_ && !stop_) {
+            Slot &s = ring_[next_claim_ % ring_.size()];
+            s.error = "cannot initialise zlib";
+            s.out.clear();
+            s.ready = true;
+            ++next_claim_;
+            end_seq_ = next_claim_;
+        }
+        lk.unlock();
+        can_consume_.notify_all();
+        can_produce_.notify_all();
+        return;
+    }
     for (;;) {
         Slot *s;
         {

@@ -995,33 +995,26 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
     if (!h || !n_parts || n_parts > 64 || (n_parts > 1 && !splitters) || !counts || (h->n_records && !dst_records))
         return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
-    int rc = ensure(h, h->d_xchg, (size_t)4096 * 8 + 2 * 64 * 8);
+    // d_xchg: 4096 sample keys | 64 splitters | 64 part totals | 64 words per partition block
+    const uint32_t blocks = ipx_partition_blocks(h->n_records);
+    int rc = ensure(h, h->d_xchg, ((size_t)4096 + 2 * 64 + (size_t)blocks * 64) * 8);
     if (rc) return rc;
     unsigned long long *d_spl = h->d_xchg.as<unsigned long long>() + 4096;
     unsigned long long *d_cnt = d_spl + 64;
-    unsigned long long host[128];
+    unsigned long long *d_blk = d_cnt + 64;
+    unsigned long long host[64];
     memset(host, 0, sizeof host);
     for (uint32_t i = 0; i + 1 < n_parts; ++i) host[i] = splitters[i];
     ProfScope prof_scope(&h->prof);
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     HIPCHK(hipMemcpyAsync(d_spl, host, sizeof host, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(ipx_launch_partition_count(h->stream, h->items_a.as<uint4>(), h->n_records, h->key, n_parts, d_spl, d_cnt));
+    HIPCHK(ipx_launch_partition(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->n_records, h->key, n_parts,
+                                d_spl, d_blk, d_cnt, (uint4 *)dst_records));
     HIPCHK(hipMemcpyAsync(h->pin_small, d_cnt, 64 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(ipx_stream_wait(h->stream));
     h->prof.collect();
-    ipx_prof_mark(h->stream, IPXK_BEGIN);
     const unsigned long long *c = (const unsigned long long *)h->pin_small;
-    unsigned long long off = 0;
-    for (uint32_t i = 0; i < n_parts; ++i) {
-        counts[i] = c[i];
-        host[64 + i] = off;              // cursors start at the parts' offsets
-        off += c[i];
-    }
-    HIPCHK(hipMemcpyAsync(d_cnt, host + 64, 64 * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(ipx_launch_partition_scatter(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->n_records, h->key,
-                                        n_parts, d_spl, d_cnt, (uint4 *)dst_records));
-    HIPCHK(ipx_stream_wait(h->stream));
-    h->prof.collect();
+    for (uint32_t i = 0; i < n_parts; ++i) counts[i] = c[i];
     return IPX_OK;
 }
 

@@ -229,13 +229,13 @@ hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out,
 // ipx_exchange.hip: key-range partitioning of the pending records for the multi-GPU exchange
 hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
                              uint32_t n_samples, unsigned long long *out /* device */);
-hipError_t ipx_launch_partition_count(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
-                                      uint32_t n_parts, const unsigned long long *splitters /* device */,
-                                      unsigned long long *counts /* device, n_parts, zeroed */);
-hipError_t ipx_launch_partition_scatter(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
-                                        const KeyLayout &kl, uint32_t n_parts,
-                                        const unsigned long long *splitters /* device */,
-                                        unsigned long long *cursors /* device, n_parts: start offsets */,
-                                        uint4 *out_records /* 2 uint4 per record */);
+uint32_t ipx_partition_blocks(uint64_t n);
+// count, plan and scatter in one go: the records (item, payload pairs) of part p end up one after the
+// other in out_records, parts in order; totals (device, 64 words) receives the part sizes.
+// blk: device scratch, 64 words per block of ipx_partition_blocks(n)
+hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
+                                const KeyLayout &kl, uint32_t n_parts,
+                                const unsigned long long *splitters /* device */, unsigned long long *blk,
+                                unsigned long long *totals, uint4 *out_records);
 hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
                             uint4 *pays, uint8_t *digs, DigitSpec first, Counters *counters);

@@ -33,9 +33,13 @@ __global__ void k_sample(const uint4 *__restrict__ items, uint64_t n, KeyLayout 
     out[i] = n ? part_key(items[idx < n ? idx : n - 1], kl) : ~0ull;
 }
 
+// Partitioning without global atomics: block b of a fixed grid owns the tiles b, b + G, b + 2G, ... (2048
+// records each) in both kernels.  k_part_count leaves every block's per-part counts, k_part_plan turns
+// them into every block's write position per part (parts laid out one after the other) and the part
+// totals, k_part_scatter replays the same tiles and places the records.
 __global__ __launch_bounds__(256) void k_part_count(const uint4 *__restrict__ items, uint64_t n, KeyLayout kl,
                                                     uint32_t n_parts, const unsigned long long *__restrict__ spl_g,
-                                                    unsigned long long *__restrict__ counts) {
+                                                    unsigned long long *__restrict__ blk) {
     __shared__ unsigned long long spl[MAX_PARTS];
     __shared__ uint32_t c[MAX_PARTS];
     if (threadIdx.x < MAX_PARTS) {
@@ -43,52 +47,102 @@ __global__ __launch_bounds__(256) void k_part_count(const uint4 *__restrict__ it
         spl[threadIdx.x] = (threadIdx.x + 1 < n_parts) ? spl_g[threadIdx.x] : ~0ull;
     }
     __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-        atomicAdd(&c[part_of(part_key(items[i], kl), spl, n_parts)], 1u);
-    __syncthreads();
-    if (threadIdx.x < n_parts && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c[threadIdx.x]);
-}
-
-// one tile of 2048 records per block iteration: count per part in LDS, reserve each part's
-// range with one atomic, then place the records (item, payload) pair by pair
-__global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ items, const uint4 *__restrict__ pays,
-                                                      uint64_t n, KeyLayout kl, uint32_t n_parts,
-                                                      const unsigned long long *__restrict__ spl_g,
-                                                      unsigned long long *__restrict__ cursors,
-                                                      uint4 *__restrict__ out) {
-    __shared__ unsigned long long spl[MAX_PARTS];
-    __shared__ uint32_t c[MAX_PARTS];
-    __shared__ unsigned long long base[MAX_PARTS];
-    if (threadIdx.x < MAX_PARTS) spl[threadIdx.x] = (threadIdx.x + 1 < n_parts) ? spl_g[threadIdx.x] : ~0ull;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint64_t n_tiles = (n + 2047) / 2048;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (threadIdx.x < MAX_PARTS) c[threadIdx.x] = 0;
-        __syncthreads();
-        uint4 it[8];
-        uint32_t part[8], local[8];
 #pragma unroll
         for (uint32_t r = 0; r < 8; ++r) {
             const uint64_t i = tile * 2048 + r * 256 + threadIdx.x;
-            part[r] = 0xffffffffu;
-            if (i < n) {
-                it[r] = items[i];
-                part[r] = part_of(part_key(it[r], kl), spl, n_parts);
-                local[r] = atomicAdd(&c[part[r]], 1u);
+            const bool ok = i < n;
+            const uint32_t part = ok ? part_of(part_key(items[i], kl), spl, n_parts) : 0xffffffffu;
+            // records arrive in scan order, i.e. nearly in genome order: a wave rarely holds more than two parts
+            unsigned long long todo = ipx_ballot(ok);
+            while (todo) {
+                const uint32_t pv = __builtin_amdgcn_readlane(part, __ffsll(todo) - 1);
+                const unsigned long long m = ipx_ballot(part == pv);
+                if (lane == (uint32_t)(__ffsll(m) - 1)) atomicAdd(&c[pv], (uint32_t)__popcll(m));
+                todo &= ~m;
             }
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_PARTS) blk[(uint64_t)blockIdx.x * MAX_PARTS + threadIdx.x] = c[threadIdx.x];
+}
+
+// one block of 1024 threads, thread b for partition block b: blk[b][p] (counts) -> blk[b][p] (where block b
+// writes part p: parts one after the other, inside a part the blocks in order), totals[p]
+__global__ __launch_bounds__(1024) void k_part_plan(unsigned long long *__restrict__ blk, uint32_t n_blocks,
+                                                    uint32_t n_parts, unsigned long long *__restrict__ totals) {
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long part_total[MAX_PARTS];
+    const uint32_t b = threadIdx.x, lane = b & 63u, wave = b >> 6;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const unsigned long long v = b < n_blocks ? blk[(uint64_t)b * MAX_PARTS + p] : 0ull;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long x = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += x;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
-        if (threadIdx.x < n_parts)
-            base[threadIdx.x] = c[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)c[threadIdx.x]) : 0ull;
+        unsigned long long before = 0, all = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < wave) before += wave_sum[w];
+            all += wave_sum[w];
+        }
+        if (b < n_blocks) blk[(uint64_t)b * MAX_PARTS + p] = before + incl - v;     // exclusive over the blocks
+        if (b == 0) part_total[p] = all;
         __syncthreads();
+    }
+    if (b < MAX_PARTS) totals[b] = b < n_parts ? part_total[b] : 0ull;
+    for (uint32_t p = 1; p < n_parts; ++p) {
+        unsigned long long off = 0;
+        for (uint32_t q = 0; q < p; ++q) off += part_total[q];
+        if (b < n_blocks) blk[(uint64_t)b * MAX_PARTS + p] += off;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ items, const uint4 *__restrict__ pays,
+                                                      uint64_t n, KeyLayout kl, uint32_t n_parts,
+                                                      const unsigned long long *__restrict__ spl_g,
+                                                      const unsigned long long *__restrict__ blk,
+                                                      uint4 *__restrict__ out) {
+    __shared__ unsigned long long spl[MAX_PARTS];
+    __shared__ unsigned long long cursor[MAX_PARTS];        // this block's next position per part
+    if (threadIdx.x < MAX_PARTS) {
+        spl[threadIdx.x] = (threadIdx.x + 1 < n_parts) ? spl_g[threadIdx.x] : ~0ull;
+        cursor[threadIdx.x] = blk[(uint64_t)blockIdx.x * MAX_PARTS + threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_tiles = (n + 2047) / 2048;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll
         for (uint32_t r = 0; r < 8; ++r) {
-            if (part[r] != 0xffffffffu) {
-                const unsigned long long pos = base[part[r]] + local[r];
-                out[2 * pos] = it[r];
-                out[2 * pos + 1] = pays[it[r].w];
+            const uint64_t i = tile * 2048 + r * 256 + threadIdx.x;
+            const bool ok = i < n;
+            uint4 it = make_uint4(0, 0, 0, 0);
+            if (ok) it = items[i];
+            const uint32_t part = ok ? part_of(part_key(it, kl), spl, n_parts) : 0xffffffffu;
+            unsigned long long pos = 0;
+            unsigned long long todo = ipx_ballot(ok);
+            while (todo) {
+                const uint32_t pv = __builtin_amdgcn_readlane(part, __ffsll(todo) - 1);
+                const unsigned long long m = ipx_ballot(part == pv);
+                const int leader = __ffsll(m) - 1;
+                unsigned long long at = 0;
+                if ((int)lane == leader) at = atomicAdd(&cursor[pv], (unsigned long long)__popcll(m));
+                at = __shfl(at, leader);
+                if (part == pv)
+                    pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                todo &= ~m;
+            }
+            if (ok) {
+                out[2 * pos] = it;
+                out[2 * pos + 1] = pays[it.w];
             }
         }
-        __syncthreads();
     }
 }
 
@@ -141,26 +195,23 @@ hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, cons
     return hipGetLastError();
 }
 
-hipError_t ipx_launch_partition_count(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
-                                      uint32_t n_parts, const unsigned long long *splitters,
-                                      unsigned long long *counts) {
-    if (n_parts > MAX_PARTS) return hipErrorInvalidValue;
-    uint64_t blocks = ipx_div_up(n ? n : 1, 2048);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_part_count, dim3((uint32_t)blocks), dim3(256), 0, s, items, n, kl, n_parts, splitters, counts);
-    ipx_prof_mark(s, IPXK_PARTITION);
-    return hipGetLastError();
+// blocks of the partition kernels: a fixed grid, the same for count, plan and scatter
+uint32_t ipx_partition_blocks(uint64_t n) {
+    const uint64_t tiles = ipx_div_up(n ? n : 1, 2048);
+    return (uint32_t)(tiles < 1024 ? tiles : 1024);
 }
 
-hipError_t ipx_launch_partition_scatter(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
-                                        const KeyLayout &kl, uint32_t n_parts, const unsigned long long *splitters,
-                                        unsigned long long *cursors, uint4 *out_records) {
+// blk: MAX_PARTS (64) words per block of ipx_partition_blocks(n); totals: 64 words
+hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
+                                const KeyLayout &kl, uint32_t n_parts, const unsigned long long *splitters,
+                                unsigned long long *blk, unsigned long long *totals, uint4 *out_records) {
     if (n_parts > MAX_PARTS) return hipErrorInvalidValue;
-    if (!n) return hipSuccess;
-    uint64_t blocks = ipx_div_up(n, 2048);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_part_scatter, dim3((uint32_t)blocks), dim3(256), 0, s, items, pays, n, kl, n_parts, splitters,
-                       cursors, out_records);
+    const uint32_t blocks = ipx_partition_blocks(n);
+    hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(256), 0, s, items, n, kl, n_parts, splitters, blk);
+    hipLaunchKernelGGL(k_part_plan, dim3(1), dim3(1024), 0, s, blk, blocks, n_parts, totals);
+    if (n)
+        hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(256), 0, s, items, pays, n, kl, n_parts, splitters, blk,
+                           out_records);
     ipx_prof_mark(s, IPXK_PARTITION);
     return hipGetLastError();
 }

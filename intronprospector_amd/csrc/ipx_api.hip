@@ -129,6 +129,8 @@ struct ipx_handle {
     DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
+    uint32_t *mail_host = nullptr, *mail_dev = nullptr;      // k_publish's mailbox (pinned, host-coherent)
+    uint32_t mail_seq = 0;
     void *pin_out = nullptr, *pin_out2 = nullptr;
     size_t pin_out_cap = 0, pin_out2_cap = 0;
     ipx_table table{};
@@ -168,11 +170,48 @@ static hipError_t ipx_stream_wait(hipStream_t s) {
     return e;
 }
 
+// Reading a few words back between stages: a copy command, its completion signal and the host's stream
+// query cost 25-45 us per stage.  Instead the LAST kernel of the stage is k_publish: it writes the words
+// straight into pinned, host-coherent memory and then a sequence number, and the host spins on that number
+// in its own memory.  Falls back to the stream wait if the number does not arrive (a faulted kernel).
+constexpr uint32_t MAIL_WORDS = 128, MAIL_SEQ = 128;         // words 0..127 payload, word 128 the sequence number
+__global__ void k_publish(const uint32_t *__restrict__ a, uint32_t na, const uint32_t *__restrict__ b, uint32_t nb,
+                          uint32_t *__restrict__ mail, uint32_t seq) {
+    const uint32_t t = threadIdx.x;
+    if (t < na) mail[t] = a[t];
+    else if (t < na + nb) mail[t] = b[t - na];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&mail[MAIL_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #define HIPCHK(call)                                                  \
     do {                                                              \
         hipError_t e__ = (call);                                      \
         if (e__ != hipSuccess) return fail_hip(h, e__, #call, __LINE__); \
     } while (0)
+
+// words a[0..na) and b[0..nb) (device) -> dst (host) once everything queued on the stream before is done
+int read_back(ipx_handle *h, void *dst, const void *a, uint32_t na, const void *b = nullptr, uint32_t nb = 0) {
+    static const bool by_copy = [] { const char *e = getenv("IPX_SYNC"); return e && (e[0] == 'b' || e[0] == 'c'); }();
+    if (by_copy || na + nb > MAIL_WORDS) {
+        if (na) HIPCHK(hipMemcpyAsync(dst, a, (size_t)na * 4, hipMemcpyDeviceToHost, h->stream));
+        if (nb) HIPCHK(hipMemcpyAsync((uint32_t *)dst + na, b, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(ipx_stream_wait(h->stream));
+        return IPX_OK;
+    }
+    const uint32_t seq = ++h->mail_seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(MAIL_WORDS), 0, h->stream, (const uint32_t *)a, na, (const uint32_t *)b, nb,
+                       h->mail_dev, seq);
+    HIPCHK(hipGetLastError());
+    bool arrived = false;
+    for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
+        if (__atomic_load_n(&h->mail_host[MAIL_SEQ], __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+    }
+    if (!arrived) HIPCHK(hipStreamSynchronize(h->stream));          // reports the fault, if that is what happened
+    memcpy(dst, h->mail_host, (size_t)(na + nb) * 4);
+    return IPX_OK;
+}
 
 int ensure(ipx_handle *h, DevBuf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0) {
     if (bytes <= b.cap) return IPX_OK;
@@ -345,6 +384,14 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
     if (hipHostMalloc(&h->pin_small, 4096, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
+    {
+        void *m = nullptr, *d = nullptr;
+        if (hipHostMalloc(&m, 4096, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
+        memset(m, 0, 4096);
+        h->mail_host = (uint32_t *)m;
+        if (hipHostGetDevicePointer(&d, m, 0) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
+        h->mail_dev = (uint32_t *)d;
+    }
     int rc = ensure(h, h->counters, IPX_COUNTERS_BYTES);      // layout: ipx_common.h
     if (!rc && hipMemsetAsync(h->counters.p, 0, IPX_COUNTERS_BYTES, h->stream) != hipSuccess) rc = IPX_EDEVICE;
     if (!rc) rc = ensure(h, h->close_ws, 2 * CLOSE_CAP * sizeof(unsigned long long));
@@ -366,6 +413,7 @@ int ipx_destroy(ipx_handle *h) {
                       &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
+    if (h->mail_host) (void)hipHostFree(h->mail_host);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_out2) (void)hipHostFree(h->pin_out2);
     for (auto &e : h->ev)
@@ -519,8 +567,7 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
                                    h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
                                    h->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
-        HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(ipx_stream_wait(h->stream));
+        if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
         const bool layout_bad = use_ops && c->pad[0] != 0;
@@ -634,8 +681,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             HIPCHK(ipx_launch_scan_u32(s, chunk_j, chunk_j, chunks, sums, tot + 0));
             HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
         }
-        HIPCHK(hipMemcpyAsync(small, tot, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(ipx_stream_wait(s));
+        if ((rc = read_back(h, small, tot, 2))) return rc;
         h->prof.collect();
         ipx_prof_mark(s, IPXK_BEGIN);
         J = small[0];
@@ -687,9 +733,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));
-        HIPCHK(hipMemcpyAsync(small, rb.totals, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(small + 8, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        HIPCHK(ipx_stream_wait(s));
+        if ((rc = read_back(h, small, rb.totals, 8, h->counters.p, sizeof(Counters) / 4))) return rc;
         h->prof.collect();
         ipx_prof_mark(s, IPXK_BEGIN);
         n_valid = small[0];
@@ -749,7 +793,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         t.motif = rb.out_motif; t.read_counts = rb.out_read_counts; t.creator_order = rb.out_creator_order;
         t.ijunc = rb.out_ijunc; t.hist_begin = rb.out_hist_begin; t.hist_value = rb.out_hist_value;
         t.hist_count = rb.out_hist_count;
-        HIPCHK(ipx_stream_wait(s));
+        if ((rc = read_back(h, small + 48, nullptr, 0))) return rc;      // completion only
     } else {
         // pinned host copy, same section layout
         Arena ha;
@@ -1010,8 +1054,7 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
     HIPCHK(hipMemcpyAsync(d_spl, host, sizeof host, hipMemcpyHostToDevice, h->stream));
     HIPCHK(ipx_launch_partition(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->n_records, h->key, n_parts,
                                 d_spl, d_blk, d_cnt, (uint4 *)dst_records));
-    HIPCHK(hipMemcpyAsync(h->pin_small, d_cnt, 64 * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(ipx_stream_wait(h->stream));
+    if ((rc = read_back(h, h->pin_small, d_cnt, 64 * 2))) return rc;
     h->prof.collect();
     const unsigned long long *c = (const unsigned long long *)h->pin_small;
     for (uint32_t i = 0; i < n_parts; ++i) counts[i] = c[i];
@@ -1032,8 +1075,7 @@ int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     HIPCHK(ipx_launch_adopt(h->stream, (const uint4 *)records, n, 0, h->items_a.as<uint4>(), h->pays.as<uint4>(),
                             h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>()));
-    HIPCHK(hipMemcpyAsync(h->pin_small, h->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(ipx_stream_wait(h->stream));
+    if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
     h->prof.collect();
     const Counters *c = (const Counters *)h->pin_small;
     for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }

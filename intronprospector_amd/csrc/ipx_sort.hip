@@ -21,6 +21,7 @@
 // correct but ~2x slower per pass than k_scatter here: look-back chains over tiles that
 // run in lockstep cost more than the separate histogram read saves.
 #include "ipx_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -137,48 +138,62 @@ __global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, ui
     if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-template <bool WRITE_NEXT>
-__global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
-                                                          uint8_t *__restrict__ dig_dst, uint64_t n, DigitSpec d,
-                                                          DigitSpec next_d, const uint32_t *__restrict__ scanned,
-                                                          const uint32_t *__restrict__ bin_total,
-                                                          uint32_t n_tiles) {
+// NT threads (NT/64 waves) move one 2048-item tile.  NT = 512: twice the waves per CU at the same LDS
+// footprint (4 tiles of 32 KiB per CU either way) and half the ranking rounds per wave.
+template <bool WRITE_NEXT, uint32_t NT>
+__global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                uint8_t *__restrict__ dig_dst, uint64_t n, DigitSpec d,
+                                                DigitSpec next_d, const uint32_t *__restrict__ scanned,
+                                                const uint32_t *__restrict__ bin_total,
+                                                uint32_t n_tiles, uint32_t xcd_ranges) {
+    constexpr uint32_t NW = NT / 64, IPT = SORT_TILE / NT, PER_WAVE = SORT_TILE / NW;
     __shared__ uint4 tile[SORT_TILE];          // 32 KiB
-    __shared__ uint32_t cnt[4][256];           // per-wave digit counts
+    __shared__ uint16_t cnt[NW][256];          // per-wave digit counts (<= PER_WAVE each)
     __shared__ uint32_t tile_excl[256];        // exclusive digit prefix inside the tile
     __shared__ uint32_t gbase[256];            // global offset of (digit, this tile)
     __shared__ uint32_t wsum[4], wsum2[4];
 
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+    // Workgroups go to the 8 XCDs round-robin by blockIdx.  Give every XCD one contiguous range of tiles:
+    // inside a digit's region the runs of neighbouring tiles are neighbours in memory, and a 64-byte sector
+    // shared by two runs is merged in L2 only if both were written through the SAME XCD's L2.
+    uint32_t tile_id = blockIdx.x;
+    if (xcd_ranges) {
+        const uint32_t x = blockIdx.x & 7u, k = blockIdx.x >> 3, q = n_tiles >> 3, r = n_tiles & 7u;
+        tile_id = x * q + (x < r ? x : r) + k;
+    }
+    const uint64_t base = (uint64_t)tile_id * SORT_TILE;
     const uint32_t valid = (uint32_t)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
 
-    for (uint32_t k = t; k < 4 * 256; k += SORT_THREADS) (&cnt[0][0])[k] = 0;
-    // global base of bin t = (items in smaller bins) + (bin-t items in earlier tiles)
-    const uint32_t my_total = bin_total[t];
-    const uint32_t my_before = scanned[(uint64_t)t * n_tiles + blockIdx.x];
-    {
-        uint32_t incl = my_total;
+    for (uint32_t k = t; k < NW * 256 / 2; k += NT) reinterpret_cast<uint32_t *>(&cnt[0][0])[k] = 0;
+    // global base of bin t = (items in smaller bins) + (bin-t items in earlier tiles); threads 0..255
+    uint32_t my_total = 0, my_before = 0, incl2 = 0;
+    if (t < 256) {
+        my_total = bin_total[t];
+        my_before = scanned[(uint64_t)t * n_tiles + tile_id];
+        incl2 = my_total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t x = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += x;
+            const uint32_t x = __shfl_up(incl2, o);
+            if ((int)lane >= o) incl2 += x;
         }
-        if (lane == 63) wsum2[wave] = incl;
-        __syncthreads();
+        if (lane == 63) wsum2[wave] = incl2;
+    }
+    __syncthreads();
+    if (t < 256) {
         uint32_t off = 0;
         for (uint32_t w = 0; w < wave; ++w) off += wsum2[w];
-        gbase[t] = off + incl - my_total + my_before;
+        gbase[t] = off + incl2 - my_total + my_before;
     }
 
-    // wave w owns tile items [w*512, w*512+512) in 8 rounds of 64: item order is
+    // wave w owns tile items [w*PER_WAVE, (w+1)*PER_WAVE) in IPT rounds of 64: item order is
     // (wave, round, lane), which is memory order -> the split is stable.
-    uint4 it[SORT_IPT];
-    uint32_t rk[SORT_IPT];                     // rank among equal digits inside the wave's chunk
-    uint32_t dg[SORT_IPT];
+    uint4 it[IPT];
+    uint32_t rk[IPT];                          // rank among equal digits inside the wave's chunk
+    uint32_t dg[IPT];
 #pragma unroll
-    for (uint32_t r = 0; r < SORT_IPT; ++r) {
-        const uint32_t li = wave * 512 + r * 64 + lane;
+    for (uint32_t r = 0; r < IPT; ++r) {
+        const uint32_t li = wave * PER_WAVE + r * 64 + lane;
         const bool ok = li < valid;
         if (ok) it[r] = src[base + li];
         const uint32_t dig = ok ? digit_of(it[r], d) : 0xffffffffu;
@@ -198,24 +213,32 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restric
             rk[r] = before + below;
         }
         __builtin_amdgcn_wave_barrier();
-        if (ok && below == 0) cnt[wave][dig] = before + (uint32_t)__popcll(peers);
+        if (ok && below == 0) cnt[wave][dig] = (uint16_t)(before + (uint32_t)__popcll(peers));
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 
     // digit totals of the tile and their exclusive prefix (one thread per digit)
-    {
-        const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
-        const uint32_t tot = c0 + c1 + c2 + c3;
-        cnt[0][t] = 0; cnt[1][t] = c0; cnt[2][t] = c0 + c1; cnt[3][t] = c0 + c1 + c2;
-        uint32_t incl = tot;
+    uint32_t tot = 0, incl = 0;
+    if (t < 256) {
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; ++w) {
+            const uint32_t c = cnt[w][t];
+            cnt[w][t] = (uint16_t)run;
+            run += c;
+        }
+        tot = run;
+        incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o);
             if ((int)lane >= o) incl += v;
         }
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (t < 256) {
         uint32_t woff = 0;
         for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
         tile_excl[t] = woff + incl - tot;
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restric
 
     // place every item at its sorted position inside the tile
 #pragma unroll
-    for (uint32_t r = 0; r < SORT_IPT; ++r) {
+    for (uint32_t r = 0; r < IPT; ++r) {
         const uint32_t dig = dg[r];
         if (dig != 0xffffffffu) tile[tile_excl[dig] + cnt[wave][dig] + rk[r]] = it[r];
     }
@@ -232,8 +255,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint4 *__restric
 
     // contiguous runs per digit leave together; the next pass's digit byte goes along
 #pragma unroll
-    for (uint32_t r = 0; r < SORT_IPT; ++r) {
-        const uint32_t slot = r * SORT_THREADS + t;
+    for (uint32_t r = 0; r < IPT; ++r) {
+        const uint32_t slot = r * NT + t;
         if (slot < valid) {
             const uint4 v = tile[slot];
             const uint32_t dig = digit_of(v, d);
@@ -351,6 +374,9 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     const uint32_t hist_grid = n_groups < 2048 ? n_groups : 2048;
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
+    static const uint32_t xcd_env = [] { const char *e = getenv("IPX_SCATTER_XCD"); return e ? (uint32_t)atoi(e) : 1u; }();
+    const uint32_t xcd_ranges = (xcd_env && n_tiles >= 64) ? 1u : 0u;
+    static const uint32_t scatter_nt = [] { const char *e = getenv("IPX_SCATTER_NT"); return e ? (uint32_t)atoi(e) : 512u; }();
     for (uint32_t k = 0; k < plan.n; ++k) {
         const DigitSpec d = plan.digits[k];
         const bool has_next = k + 1 < plan.n;
@@ -366,12 +392,14 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);
         ipx_prof_pre(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);
-        if (bytes && has_next)
-            hipLaunchKernelGGL(k_scatter<true>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d, next_d,
-                               hist, bin_total, n_tiles);
-        else
-            hipLaunchKernelGGL(k_scatter<false>, dim3(n_tiles), dim3(SORT_THREADS), 0, s, src, dst, ddst, n, d,
-                               next_d, hist, bin_total, n_tiles);
+#define IPX_SCATTER(W, NT) hipLaunchKernelGGL((k_scatter<W, NT>), dim3(n_tiles), dim3(NT), 0, s, src, dst, ddst, n, d, next_d, \
+                                             hist, bin_total, n_tiles, xcd_ranges)
+        if (bytes && has_next) {
+            if (scatter_nt == 512) IPX_SCATTER(true, 512); else IPX_SCATTER(true, 256);
+        } else {
+            if (scatter_nt == 512) IPX_SCATTER(false, 512); else IPX_SCATTER(false, 256);
+        }
+#undef IPX_SCATTER
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);
         uint4 *ti = src; src = dst; dst = ti;
         uint8_t *tb = dsrc; dsrc = ddst; ddst = tb;

@@ -310,7 +310,7 @@ __device__ __forceinline__ uint4 load_cigar4(const uint32_t *__restrict__ cigar,
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-__global__ __launch_bounds__(256) void k_scan_long(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
+__global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                                    uint32_t reads_per_wave,
                                                    const int32_t *__restrict__ a_tid,
                                                    const int32_t *__restrict__ a_pos,
@@ -1123,7 +1123,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
             const long v = e ? atol(e) : 0;
             return (uint32_t)(v >= 64 && v <= 65536 ? v : 64);
         }();
-        const uint64_t max_waves = 256ull * 3 * 4;      // all resident at once (VGPRs: 3 waves per SIMD)
+        const uint64_t max_waves = 256ull * 4 * 4;      // all resident at once (128 VGPRs: 4 waves per SIMD)
         uint64_t per_wave = ipx_div_up(b.n_alignments, max_waves);
         if (per_wave < min_range) per_wave = min_range;
         // few alignments per lane: whole multiples of 64, or one lane's second alignment doubles the wave's time

@@ -37,11 +37,12 @@ __device__ __forceinline__ uint32_t digit_of(const uint4 &it, const DigitSpec &d
 // A block counts GROUP consecutive tiles and then writes, per bin, the group's counts side by side
 // (hist is bin-major: with single tiles a block writes 256 lone 4-byte words).  The group's loads are
 // issued together; small inputs use GROUP = 1 to have enough blocks.
-template <bool BYTES, uint32_t GROUP>
+template <bool BYTES, uint32_t GROUP, uint32_t TILE>
 __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__ items,
                                                        const uint8_t *__restrict__ digs, uint64_t n,
                                                        DigitSpec d, uint32_t *__restrict__ hist,
                                                        uint32_t n_tiles) {
+    constexpr uint32_t BPT = TILE / SORT_THREADS, WPT = BPT / 4;      // digit bytes (words) per thread and tile
     __shared__ uint32_t hs[GROUP][256];
     const uint32_t n_groups = (n_tiles + GROUP - 1) / GROUP;
     for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
@@ -50,46 +51,54 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
         __syncthreads();
         const uint32_t tile0 = group * GROUP;
         if (BYTES) {
-            uint2 v[GROUP];
+            uint32_t v[GROUP][WPT];
             bool whole[GROUP];
 #pragma unroll
             for (uint32_t g = 0; g < GROUP; ++g) {
-                const uint64_t i0 = (uint64_t)(tile0 + g) * SORT_TILE + (uint64_t)threadIdx.x * 8;
-                whole[g] = tile0 + g < n_tiles && i0 + 8 <= n;
-                v[g] = whole[g] ? *reinterpret_cast<const uint2 *>(digs + i0) : make_uint2(0, 0);   // tile bases are 2048-aligned
+                const uint64_t i0 = (uint64_t)(tile0 + g) * TILE + (uint64_t)threadIdx.x * BPT;
+                whole[g] = tile0 + g < n_tiles && i0 + BPT <= n;
+                // tile bases are TILE-aligned: one 8- or 16-byte load
+                if (WPT == 2) {
+                    const uint2 x = whole[g] ? *reinterpret_cast<const uint2 *>(digs + i0) : make_uint2(0, 0);
+                    v[g][0] = x.x; v[g][1] = x.y;
+                } else {
+                    const uint4 x = whole[g] ? *reinterpret_cast<const uint4 *>(digs + i0) : make_uint4(0, 0, 0, 0);
+                    v[g][0] = x.x; v[g][1] = x.y; v[g][WPT - 2] = x.z; v[g][WPT - 1] = x.w;
+                }
             }
 #pragma unroll
             for (uint32_t g = 0; g < GROUP; ++g) {
                 uint32_t *h = hs[g];
                 if (whole[g]) {
-                    // high digits of (nearly) sorted keys: the thread's 8 bytes, often the whole wave's,
-                    // are one value -> one LDS add instead of 8 (512) on a single, contended bin
-                    const uint32_t b0 = v[g].x & 0xffu;
-                    const bool uni = (v[g].x == b0 * 0x01010101u) && (v[g].y == v[g].x);
+                    // high digits of (nearly) sorted keys: the thread's bytes, often the whole wave's,
+                    // are one value -> one LDS add instead of BPT (64 * BPT) on a single, contended bin
+                    const uint32_t b0 = v[g][0] & 0xffu;
+                    bool uni = true;
+#pragma unroll
+                    for (uint32_t w = 0; w < WPT; ++w) uni = uni && (v[g][w] == b0 * 0x01010101u);
                     const uint64_t act = ipx_ballot(1);
                     const uint32_t first = __builtin_amdgcn_readfirstlane(b0);
                     if (ipx_ballot(uni && b0 == first) == act) {
                         if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)act) - 1))
-                            atomicAdd(&h[first], 8u * (uint32_t)__popcll(act));
+                            atomicAdd(&h[first], BPT * (uint32_t)__popcll(act));
                     } else if (uni) {
-                        atomicAdd(&h[b0], 8u);
+                        atomicAdd(&h[b0], BPT);
                     } else {
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            atomicAdd(&h[(v[g].x >> (8 * k)) & 0xffu], 1u);
-                            atomicAdd(&h[(v[g].y >> (8 * k)) & 0xffu], 1u);
-                        }
+                        for (uint32_t w = 0; w < WPT; ++w)
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) atomicAdd(&h[(v[g][w] >> (8 * k)) & 0xffu], 1u);
                     }
                 } else if (tile0 + g < n_tiles) {
-                    const uint64_t i0 = (uint64_t)(tile0 + g) * SORT_TILE + (uint64_t)threadIdx.x * 8;
-                    for (uint64_t i = i0; i < n && i < i0 + 8; ++i) atomicAdd(&h[digs[i]], 1u);
+                    const uint64_t i0 = (uint64_t)(tile0 + g) * TILE + (uint64_t)threadIdx.x * BPT;
+                    for (uint64_t i = i0; i < n && i < i0 + BPT; ++i) atomicAdd(&h[digs[i]], 1u);
                 }
             }
         } else {
             for (uint32_t g = 0; g < GROUP && tile0 + g < n_tiles; ++g) {
-                const uint64_t base = (uint64_t)(tile0 + g) * SORT_TILE;
+                const uint64_t base = (uint64_t)(tile0 + g) * TILE;
 #pragma unroll
-                for (uint32_t r = 0; r < SORT_IPT; ++r) {
+                for (uint32_t r = 0; r < BPT; ++r) {
                     const uint64_t i = base + r * SORT_THREADS + threadIdx.x;
                     if (i < n) atomicAdd(&hs[g][digit_of(items[i], d)], 1u);
                 }
@@ -138,16 +147,18 @@ __global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, ui
     if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-// NT threads (NT/64 waves) move one 2048-item tile.  NT = 512: twice the waves per CU at the same LDS
-// footprint (4 tiles of 32 KiB per CU either way) and half the ranking rounds per wave.
-template <bool WRITE_NEXT, uint32_t NT>
+// NT threads (NT/64 waves) move one TILE-item tile; a CU holds 128 KiB of tiles either way.  More waves per
+// tile mean more waves per CU at the same LDS footprint and fewer ranking rounds per wave (256 threads on
+// 2048 items: 16 waves per CU, 81 us per pass on S; 512 threads: 32 waves, 69 us).  Larger tiles mean longer
+// runs per digit (TILE/256 items on uniform digits) and fewer rows in the histogram.
+template <bool WRITE_NEXT, uint32_t NT, uint32_t TILE>
 __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                 uint8_t *__restrict__ dig_dst, uint64_t n, DigitSpec d,
                                                 DigitSpec next_d, const uint32_t *__restrict__ scanned,
                                                 const uint32_t *__restrict__ bin_total,
                                                 uint32_t n_tiles, uint32_t xcd_ranges) {
-    constexpr uint32_t NW = NT / 64, IPT = SORT_TILE / NT, PER_WAVE = SORT_TILE / NW;
-    __shared__ uint4 tile[SORT_TILE];          // 32 KiB
+    constexpr uint32_t NW = NT / 64, IPT = TILE / NT, PER_WAVE = TILE / NW;
+    __shared__ uint4 tile[TILE];               // 32 or 64 KiB
     __shared__ uint16_t cnt[NW][256];          // per-wave digit counts (<= PER_WAVE each)
     __shared__ uint32_t tile_excl[256];        // exclusive digit prefix inside the tile
     __shared__ uint32_t gbase[256];            // global offset of (digit, this tile)
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, u
         const uint32_t x = blockIdx.x & 7u, k = blockIdx.x >> 3, q = n_tiles >> 3, r = n_tiles & 7u;
         tile_id = x * q + (x < r ? x : r) + k;
     }
-    const uint64_t base = (uint64_t)tile_id * SORT_TILE;
-    const uint32_t valid = (uint32_t)((n - base) < SORT_TILE ? (n - base) : SORT_TILE);
+    const uint64_t base = (uint64_t)tile_id * TILE;
+    const uint32_t valid = (uint32_t)((n - base) < TILE ? (n - base) : TILE);
 
     for (uint32_t k = t; k < NW * 256 / 2; k += NT) reinterpret_cast<uint32_t *>(&cnt[0][0])[k] = 0;
     // global base of bin t = (items in smaller bins) + (bin-t items in earlier tiles); threads 0..255
@@ -365,12 +376,21 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
                            size_t workspace_bytes, int prof_all) {
     if (n == 0 || plan.n == 0) return hipSuccess;
     if (ipx_sort_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
-    const uint32_t n_tiles = (uint32_t)ipx_div_up(n, SORT_TILE);
+    // large inputs: 4096-item tiles moved by 1024 threads (IPX_SORT_TILE=2048 keeps the small tile)
+    const char *tile_e = getenv("IPX_SORT_TILE");               // tests force either tile size
+    const uint32_t tile_env = tile_e ? (uint32_t)atoi(tile_e) : 0u;
+    const bool big = tile_env ? tile_env == 4096 : n >= (4u << 20);
+    const uint32_t tile_items = big ? 4096u : SORT_TILE;
+    const uint32_t n_tiles = (uint32_t)ipx_div_up(n, tile_items);
     uint32_t *hist = (uint32_t *)workspace;
     uint32_t *bin_total = hist + (uint64_t)256 * n_tiles;
     const bool bytes = dig_a != nullptr && dig_b != nullptr;
-    const bool grouped = n_tiles >= 2048;                 // 8 tiles per block once that leaves >= 256 blocks
-    const uint32_t n_groups = grouped ? (n_tiles + 7) / 8 : n_tiles;
+    // small tiles: 8 per histogram block (16 KiB of digit bytes) once that leaves >= 256 blocks; large
+    // tiles: one (measured on S, per step of 8 passes: 1 tile 0.106 ms, 2 0.114, 4 0.118, 8 0.134)
+    const char *ge = getenv("IPX_HIST_GROUP");
+    const uint32_t group = ge ? (uint32_t)atoi(ge) : (big ? 1u : 8u);
+    const bool grouped = (uint64_t)n_tiles * tile_items >= (4u << 20);
+    const uint32_t n_groups = grouped ? (n_tiles + group - 1) / group : n_tiles;
     const uint32_t hist_grid = n_groups < 2048 ? n_groups : 2048;
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
@@ -382,22 +402,35 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
         const bool has_next = k + 1 < plan.n;
         const DigitSpec next_d = has_next ? plan.digits[k + 1] : DigitSpec{0, 8, 0, 0};
         const bool from_bytes = bytes && (k > 0 || first_bytes_valid);
-#define IPX_HIST(B, G) hipLaunchKernelGGL((k_hist<B, G>), dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles)
-        if (from_bytes && grouped) IPX_HIST(true, 8);
-        else if (from_bytes) IPX_HIST(true, 1);
-        else if (grouped) IPX_HIST(false, 8);
-        else IPX_HIST(false, 1);
+#define IPX_HIST(B, G, T) hipLaunchKernelGGL((k_hist<B, G, T>), dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles)
+        if (big) {
+            if (from_bytes && grouped && group == 2) IPX_HIST(true, 2, 4096);
+            else if (from_bytes && grouped && group == 1) IPX_HIST(true, 1, 4096);
+            else if (from_bytes && grouped && group == 8) IPX_HIST(true, 8, 4096);
+            else if (from_bytes && grouped) IPX_HIST(true, 4, 4096);
+            else if (from_bytes) IPX_HIST(true, 1, 4096);
+            else if (grouped) IPX_HIST(false, 4, 4096);
+            else IPX_HIST(false, 1, 4096);
+        } else {
+            if (from_bytes && grouped) IPX_HIST(true, 8, 2048);
+            else if (from_bytes) IPX_HIST(true, 1, 2048);
+            else if (grouped) IPX_HIST(false, 8, 2048);
+            else IPX_HIST(false, 1, 2048);
+        }
 #undef IPX_HIST
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_HIST);
         hipLaunchKernelGGL(k_binscan, dim3(256), dim3(256), 0, s, hist, n_tiles, bin_total);
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCAN);
         ipx_prof_pre(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);
-#define IPX_SCATTER(W, NT) hipLaunchKernelGGL((k_scatter<W, NT>), dim3(n_tiles), dim3(NT), 0, s, src, dst, ddst, n, d, next_d, \
-                                             hist, bin_total, n_tiles, xcd_ranges)
-        if (bytes && has_next) {
-            if (scatter_nt == 512) IPX_SCATTER(true, 512); else IPX_SCATTER(true, 256);
+#define IPX_SCATTER(W, NT, T) hipLaunchKernelGGL((k_scatter<W, NT, T>), dim3(n_tiles), dim3(NT), 0, s, src, dst, ddst, n, d, next_d, \
+                                                hist, bin_total, n_tiles, xcd_ranges)
+        const bool w = bytes && has_next;
+        if (big) {
+            if (w) IPX_SCATTER(true, 1024, 4096); else IPX_SCATTER(false, 1024, 4096);
+        } else if (scatter_nt == 512) {
+            if (w) IPX_SCATTER(true, 512, 2048); else IPX_SCATTER(false, 512, 2048);
         } else {
-            if (scatter_nt == 512) IPX_SCATTER(false, 512); else IPX_SCATTER(false, 256);
+            if (w) IPX_SCATTER(true, 256, 2048); else IPX_SCATTER(false, 256, 2048);
         }
 #undef IPX_SCATTER
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);

@@ -409,6 +409,24 @@ def test_ijunc_by_radix_sort_when_the_bitmap_does_not_apply(monkeypatch):
     helpers.compare_tables(dev, ora)
 
 
+@pytest.mark.parametrize("tile", ["2048", "4096"])
+def test_both_sort_tile_sizes_on_small_and_ragged_inputs(monkeypatch, tile):
+    """The radix passes move 2048-item tiles (512 threads) on small inputs and 4096-item tiles (1024
+    threads) from 4 M records on; IPX_SORT_TILE forces either one, here on record counts that are not a
+    multiple of the tile and on one that is smaller than a tile."""
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_SORT_TILE", tile)
+    for reads, seed in ((70_001, 61), (1_500, 62), (263_000, 63)):
+        batch, names, _ = synth.short_reads(reads, seed=seed, n_targets=3, target_len=6_000_000, n_sites=2500)
+        dev, ora, err = _run_both(batch, names, {}, n_push=2)
+        assert err is None
+        helpers.compare_tables(dev, ora)
+    batch, names, _ = synth.long_reads(900, seed=64, n_targets=2, target_len=9_000_000, n_transcripts=40)
+    dev, ora, err = _run_both(batch, names, {"max_anchor_indel_size": 36})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
 def test_per_operation_scan_kernel_matches_oracle(monkeypatch):
     """ipx_scan_ops.hip (one lane per CIGAR operation, IPX_SCAN=ops) against the oracle on short,
     long and quirk inputs; it must also fall back cleanly on a CIGAR array that is not laid out

@@ -126,7 +126,7 @@ struct ipx_handle {
     // holds records; an empty handle takes `first_hint`: the window the last sort would have liked
     // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
     DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
-    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws;
+    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws, defer;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
     uint32_t *mail_host = nullptr, *mail_dev = nullptr;      // k_publish's mailbox (pinned, host-coherent)
@@ -410,7 +410,7 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
-                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws})
+                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->mail_host) (void)hipHostFree(h->mail_host);
@@ -556,6 +556,8 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     for (int k = 0; k < 3; ++k) { before.key_or[k] = h->key_or[k]; before.key_and[k] = h->key_and[k]; }
     bool use_ops = !h->force_lane_scan;
     bool use_stripes = true;
+    // list of the alignments k_scan_short hands on to k_scan_rest (at most all of them)
+    if ((rc = ensure(h, h->defer, (size_t)db.n_alignments * sizeof(uint32_t) + 256))) return rc;
     for (int attempt = 0; attempt < 5; ++attempt) {
         ipx_prof_mark(h->stream, IPXK_BEGIN);
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
@@ -565,13 +567,27 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
         else
             HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
                                    h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
-                                   h->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP));
+                                   h->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
+                                   h->defer.as<uint32_t>()));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
-        if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
+        const uint32_t *defer_n_dev = reinterpret_cast<const uint32_t *>(h->counters.as<char>() + IPX_CNT_DEFER);
+        if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, defer_n_dev, 1))) return rc;
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
         const bool layout_bad = use_ops && c->pad[0] != 0;
-        const bool stripes_bad = c->pad[1] != 0;           // more gaps between the stripes than the lists hold
+        bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
+        // second stage: alignments the short-CIGAR kernel only listed (more than 8 ops, overflowing tiles)
+        const uint32_t n_defer = use_ops ? 0u : ((const uint32_t *)h->pin_small)[sizeof(Counters) / 4];
+        if (n_defer && !layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
+            HIPCHK(ipx_launch_scan_rest(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                                        h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
+                                        c->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
+                                        h->defer.as<uint32_t>(), n_defer));
+            HIPCHK(hipEventRecord(h->ev[1], h->stream));
+            if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
+            h->prof.collect();
+            stripes_bad = c->pad[1] != 0;
+        }
         if (!layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->err_word_host = c->err_word;

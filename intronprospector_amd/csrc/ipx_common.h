@@ -75,8 +75,10 @@ struct ScanParams {
 constexpr uint32_t IPX_STRIPES = 8;
 constexpr uint32_t IPX_STRIPE_CHUNK_BITS = 11;       // 2048 records: stripe s owns chunks s, s + 8, s + 16, ...
 // The Counters allocation (2 KiB): Counters at 0, the copy of the CIGAR array's tail at 128 (ipx_scan.hip),
-// stripe counters at 256 + 128 * s, gap-closing counters at 1280 / 1408.
-constexpr uint32_t IPX_COUNTERS_BYTES = 2048, IPX_CNT_TAIL = 128, IPX_CNT_STRIPE0 = 256, IPX_CNT_CLOSE = 1280;
+// stripe counters at 256 + 128 * s, gap-closing counters at 1280 / 1408, length of the list of alignments
+// k_scan_short leaves to k_scan_rest at 1536.
+constexpr uint32_t IPX_COUNTERS_BYTES = 2048, IPX_CNT_TAIL = 128, IPX_CNT_STRIPE0 = 256, IPX_CNT_CLOSE = 1280,
+                   IPX_CNT_DEFER = 1536;
 
 // device-side counters of one handle (one cache line apart is not needed: they
 // are touched once per wave at most)
@@ -203,11 +205,16 @@ void ipx_prof_pre(hipStream_t s, int id);
 // ---- launchers implemented in the kernel translation units -------------------
 // ipx_scan.hip
 // p.n_stripes / p.base are set by the launcher (striped when the grid is large and close_ws is given;
-// close_ws: room for 2 * close_cap 64-bit entries)
+// close_ws: room for 2 * close_cap 64-bit entries; defer: room for one uint32 per alignment of the batch)
 hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
-                           unsigned long long *close_ws, uint64_t close_cap);
+                           unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer);
+// second stage after a short-CIGAR launch whose counters show n_defer > 0 listed alignments (IPX_CNT_DEFER)
+hipError_t ipx_launch_scan_rest(hipStream_t s, ScanParams p, const ipx_batch &b, const uint32_t *rank_of_tid,
+                                uint4 *items, uint4 *pays, uint8_t *digs, uint64_t capacity, Counters *counters,
+                                uint64_t n_records_before, unsigned long long *close_ws, uint64_t close_cap,
+                                const uint32_t *defer, uint32_t n_defer);
 
 // ipx_scan_ops.hip: the same scan with one lane per CIGAR operation (needs back-to-back CIGAR
 // words; raises Counters::pad[0] otherwise and the caller re-runs ipx_launch_scan)

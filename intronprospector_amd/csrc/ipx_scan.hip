@@ -11,6 +11,7 @@
 //
 // Mapping: one lane per alignment; see k_scan below for the tile structure.
 #include "ipx_common.h"
+#include <algorithm>
 
 #include <cstdlib>
 
@@ -295,10 +296,13 @@ struct __attribute__((packed, aligned(4))) Words4 { uint32_t x, y, z, w; };
 
 // copy of the last (up to) 8 CIGAR words followed by zero words (see ipx_launch_scan): a 16-byte load
 // that would reach past the end of the array reads here instead
-__global__ void k_cigar_tail(const uint32_t *__restrict__ cigar, uint64_t n_words, uint32_t *__restrict__ tail) {
+// (also starts the launch's list of deferred alignments at zero, see k_scan_rest)
+__global__ void k_cigar_tail(const uint32_t *__restrict__ cigar, uint64_t n_words, uint32_t *__restrict__ tail,
+                             uint32_t *__restrict__ defer_n) {
     const uint32_t t = threadIdx.x;
     const uint64_t tb = n_words >= 8 ? n_words - 8 : 0;
     if (t < 16) tail[t] = (tb + t < n_words) ? cigar[tb + t] : 0u;
+    if (t == 16) *defer_n = 0;
 }
 
 // four words starting at word w of the CIGAR array (w < n_words); only the address is selected
@@ -631,9 +635,63 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
 // eight ops run unrolled (the wave leaves when all its lanes are done); 8 ops of < 2^28 cannot carry
 // out of 32-bit offsets.  A finished junction is snapshotted; snapshots are QC'd, packed and stored for
 // all lanes of the wave at once -- when a lane is about to finish a second junction, and at the end.
-// Alignments with more than 8 ops in such a batch (a few per cent at most) take run_read<2>.
+// Alignments with more than 8 ops in such a batch (a few per cent at most), and whole tiles whose records
+// overflow the pool, are only LISTED (defer[], counted at IPX_CNT_DEFER) and left to k_scan_rest: with the
+// op-by-op walk inlined here the kernel needed 117 VGPRs (4 waves per SIMD), without it 87 (5 waves).
+struct AlnArrays {
+    const int32_t *__restrict__ tid;
+    const int32_t *__restrict__ pos;
+    const uint16_t *__restrict__ flag;
+    const uint8_t *__restrict__ xs;
+    const uint8_t *__restrict__ nh;
+    const uint32_t *__restrict__ off;
+    const uint32_t *__restrict__ nc;
+    const uint32_t *__restrict__ rank_of_tid;
+    uint64_t n, n_words, base_read_index;
+};
+
+// the per-read gate (junctions_extractor.cc:536), strand and category of alignment i; nc = 0: nothing to walk
+__device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArrays &a, uint64_t i, ReadCtx &c,
+                                              uint32_t &nc, uint32_t &off, unsigned long long &err) {
+    c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = a.base_read_index + i;
+    nc = 0; off = 0;
+    if (i < a.n) {
+        const int32_t tid = a.tid[i];
+        c.flag = a.flag[i];
+        nc = a.nc[i];
+        // junctions_extractor.cc:536
+        if (nc <= 1 || tid < 0 || (c.flag & (F_QCFAIL | F_DUP))) nc = 0;
+        if (nc) {
+            if ((uint32_t)tid >= p.n_targets) {
+                const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
+                err = e < err ? e : err;
+                nc = 0;
+            } else {
+                c.pos = a.pos[i];
+                off = a.off[i];
+                if ((uint64_t)off + nc > a.n_words) {          // words outside the batch: never dereferenced
+                    const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
+                    err = e < err ? e : err;
+                    nc = 0;
+                }
+                c.nhc = a.nh[i];
+                c.rank = a.rank_of_tid[tid];
+                const uint32_t xs = a.xs[i];
+                c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
+                                                            : (xs ? xs : (uint32_t)'.');
+            }
+        }
+    }
+    c.cat = read_category(c.flag, c.nhc);
+    c.read_rejected = (c.flag & F_SECONDARY) || (p.exclude_multi && c.nhc == 2);
+}
+
+__device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
+    return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c) + IPX_CNT_DEFER);
+}
+
 template <uint32_t RPT, uint32_t POOL, uint32_t BT>
-__global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
+__global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                                     const int32_t *__restrict__ a_tid,
                                                     const int32_t *__restrict__ a_pos,
                                                     const uint16_t *__restrict__ a_flag,
@@ -646,18 +704,16 @@ __global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uin
                                                     const uint32_t *__restrict__ rank_of_tid,
                                                     uint4 *__restrict__ items, uint4 *__restrict__ pays,
                                                     uint8_t *__restrict__ digs,
-                                                    uint64_t capacity, Counters *counters) {
+                                                    uint64_t capacity, Counters *counters,
+                                                    uint32_t *__restrict__ defer) {
     constexpr uint32_t NW = BT / 64;                 // waves per block
-    __shared__ uint32_t wsum[RPT][NW];
     __shared__ uint32_t kb_s[NW][6];
     KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
-    __shared__ uint32_t cnt_s[RPT][BT], base_s[RPT][BT];
     __shared__ unsigned long long tile_slot;
     __shared__ uint4 pool_item[POOL], pool_pay[POOL];
     __shared__ uint32_t pool_n;
     __shared__ uint16_t cx_list[BT * RPT];       // tile-local indices of the alignments that need the walk
     __shared__ uint32_t cx_n;
-    const Pool pool{pool_item, pool_pay, &pool_n, POOL};
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + (uint64_t)BT * RPT - 1) / ((uint64_t)BT * RPT);
     const uint32_t stripe = my_stripe(p);
@@ -669,38 +725,9 @@ __global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uin
         return __shfl(base, first) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     };
 
+    const AlnArrays aln{a_tid, a_pos, a_flag, a_xs, a_nh, a_off, a_nc, rank_of_tid, n, n_words, base_read_index};
     auto load_ctx = [&](uint64_t i, ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
-        c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = base_read_index + i;
-        nc = 0; off = 0;
-        if (i < n) {
-            const int32_t tid = a_tid[i];
-            c.flag = a_flag[i];
-            nc = a_nc[i];
-            // junctions_extractor.cc:536
-            if (nc <= 1 || tid < 0 || (c.flag & (F_QCFAIL | F_DUP))) nc = 0;
-            if (nc) {
-                if ((uint32_t)tid >= p.n_targets) {
-                    const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
-                    err = e < err ? e : err;
-                    nc = 0;
-                } else {
-                    c.pos = a_pos[i];
-                    off = a_off[i];
-                    if ((uint64_t)off + nc > n_words) {          // words outside the batch: never dereferenced
-                        const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
-                        err = e < err ? e : err;
-                        nc = 0;
-                    }
-                    c.nhc = a_nh[i];
-                    c.rank = rank_of_tid[tid];
-                    const uint32_t xs = a_xs[i];
-                    c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
-                                                                : (xs ? xs : (uint32_t)'.');
-                }
-            }
-        }
-        c.cat = read_category(c.flag, c.nhc);
-        c.read_rejected = (c.flag & F_SECONDARY) || (p.exclude_multi && c.nhc == 2);
+        load_read_ctx(p, aln, i, c, nc, off, err);
     };
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -874,9 +901,14 @@ __global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uin
             if (ipx_ballot(active)) step(wb.z);
             if (ipx_ballot(active)) step(wb.w);
             if (ipx_ballot(pending)) drain();
-            // CIGARs of more than 8 ops in a short-CIGAR batch: the op-by-op walk
-            if (ipx_ballot(nc > 8)) {
-                if (nc > 8) (void)run_read<2>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err, &pool);
+            // CIGARs of more than 8 ops in a short-CIGAR batch: listed for k_scan_rest's op-by-op walk
+            const unsigned long long dm = ipx_ballot(nc > 8);
+            if (dm) {
+                const int first = __ffsll(dm) - 1;
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(defer_counter(counters), (uint32_t)__popcll(dm));
+                base = __shfl(base, first);
+                if (nc > 8) defer[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = (uint32_t)i;
             }
         }
         __syncthreads();
@@ -898,51 +930,33 @@ __global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uin
                 }
             }
         } else {
-            // the pool overflowed: count, reserve, re-run (k_scan's scheme); errors were collected above
-#pragma unroll 1
-            for (uint32_t r = 0; r < RPT; ++r) {
-                const uint64_t i = tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t;
-                unsigned long long dummy = IPX_ERRW_NONE;
-                ReadCtx c;
-                uint32_t nc, off;
-                load_ctx(i, c, nc, off, dummy);
-                const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, dummy) : 0;
-                cnt_s[r][t] = cn;
-                uint32_t v = cn;
+            // the pool overflowed: nothing of it is stored, the tile's alignments go to k_scan_rest (those
+            // of more than 8 ops are on its list already)
+            const uint64_t tile_base = tile * ((uint64_t)BT * RPT);
+            uint32_t mine_n = 0;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t x = __shfl_up(v, o);
-                    if ((int)lane >= o) v += x;
-                }
-                base_s[r][t] = v - cn;
-                if (lane == 63) wsum[r][wave] = v;
-            }
-            __syncthreads();
-            uint32_t tile_total = 0;
-#pragma unroll 1
             for (uint32_t r = 0; r < RPT; ++r) {
-                uint32_t before = tile_total;
-                for (uint32_t w = 0; w < NW; ++w) {
-                    const uint32_t sw = wsum[r][w];
-                    if (w < wave) before += sw;
-                    tile_total += sw;
-                }
-                base_s[r][t] += before;
+                const uint64_t i = tile_base + (uint64_t)r * BT + t;
+                mine_n += (i < n && a_nc[i] <= 8) ? 1u : 0u;
             }
-            if (t == 0) tile_slot = tile_total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)tile_total) : 0ull;
+            // block-wide exclusive prefix of mine_n (NW waves)
+            uint32_t incl = mine_n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += x;
+            }
+            if (lane == 63) kb_s[wave][0] = incl;
             __syncthreads();
-            const uint64_t slot = tile_slot;
-#pragma unroll 1
+            uint32_t before = 0, all = 0;
+            for (uint32_t w = 0; w < NW; ++w) { const uint32_t sw = kb_s[w][0]; if (w < wave) before += sw; all += sw; }
+            if (t == 0) tile_slot = all ? atomicAdd(defer_counter(counters), all) : 0u;
+            __syncthreads();
+            uint32_t at = (uint32_t)tile_slot + before + incl - mine_n;
+#pragma unroll
             for (uint32_t r = 0; r < RPT; ++r) {
-                if (cnt_s[r][t]) {
-                    const uint64_t i = tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t;
-                    unsigned long long dummy = IPX_ERRW_NONE;
-                    ReadCtx c;
-                    uint32_t nc, off;
-                    load_ctx(i, c, nc, off, dummy);
-                    (void)run_read<1>(p, c, cigar + off, nc, slot + base_s[r][t], capacity, items, pays, digs, kb, dummy,
-                                      nullptr, nullptr, stripe);
-                }
+                const uint64_t i = tile_base + (uint64_t)r * BT + t;
+                if (i < n && a_nc[i] <= 8) defer[at++] = (uint32_t)i;
             }
         }
         unsigned long long e = my_err;
@@ -970,6 +984,75 @@ __global__ __launch_bounds__(BT) void k_scan_short(ScanParams p, uint64_t n, uin
             if (o) atomicOr(&counters->key_or[t], o);
         } else {
             if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+        }
+    }
+}
+
+// ---- what k_scan_short left out ------------------------------------------------------------------
+// k_scan_rest: the alignments k_scan_short listed (more than 8 CIGAR ops; every alignment of a tile whose
+// records overflowed the LDS pool), one lane each, op by op: count (run_read<0>), ONE reservation per wave,
+// store (run_read<1>).  Launched only when the first stage listed something (ipx_launch_scan_rest): the
+// op-by-op walk uses scratch memory, and even an empty launch of it costs 18 us.
+__global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, const uint32_t *__restrict__ cigar,
+                                                   const uint32_t *__restrict__ defer,
+                                                   uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                                   uint8_t *__restrict__ digs, uint64_t capacity, Counters *counters) {
+    const uint32_t n_def = *defer_counter(counters);
+    if (n_def == 0) return;
+    __shared__ uint32_t kb_s[4][6];
+    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t stripe = my_stripe(p);
+    unsigned long long my_err = IPX_ERRW_NONE;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t e0 = ((uint64_t)blockIdx.x * 4 + wave) * 64; e0 < n_def; e0 += stride) {
+        const bool mine = e0 + lane < n_def;
+        const uint64_t i = mine ? defer[e0 + lane] : 0u;
+        ReadCtx c;
+        uint32_t nc = 0, off = 0;
+        load_read_ctx(p, a, i, c, nc, off, my_err);
+        if (!mine) nc = 0;
+        const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err) : 0;
+        uint32_t incl = cn;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += x;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        unsigned long long slot = 0;
+        if (lane == 63 && total) slot = atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total);
+        slot = __shfl(slot, 63);
+        if (cn) {
+            unsigned long long dummy = IPX_ERRW_NONE;
+            (void)run_read<1>(p, c, cigar + off, nc, slot + (incl - cn), capacity, items, pays, digs, kb, dummy,
+                              nullptr, nullptr, stripe);
+        }
+    }
+    unsigned long long e = my_err;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(e, d);
+        e = o < e ? o : e;
+    }
+    if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const uint32_t o = __shfl_xor(v[k], dlt);
+            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
+        }
+        if (lane == 0) kb_s[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (t < 6) {
+        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        if (t < 3) {
+            const uint32_t o = x0 | x1 | x2 | x3;
+            if (o) atomicOr(&counters->key_or[t], o);
+        } else {
+            const uint32_t a4 = x0 & x1 & x2 & x3;
+            if (a4 != ~0u) atomicAnd(&counters->key_and[t - 3], a4);
         }
     }
 }
@@ -1076,14 +1159,22 @@ __global__ void k_close_finish(Counters *counters, uint64_t base, uint64_t capac
 hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
-                           unsigned long long *close_ws, uint64_t close_cap) {
+                           unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer) {
     if (b.n_alignments == 0) return hipSuccess;
     // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
-    const bool short_reads = b.n_cigar_words <= 16 * b.n_alignments;      // (the long kernel needs >= 8 words)
+    // Which kernel: the short-CIGAR kernel walks at most 8 ops per alignment itself and hands longer ones to a
+    // slow second stage, so it is for batches where those are rare.  Measured on 2 M random CIGARs
+    // (profiles/mid_cigar_timing.py): 2-8 ops short 0.12 ms / long 0.16 ms; 4-12 ops 0.37 / 0.18; 6-16 ops
+    // 0.40 / 0.20; 10-20 ops 0.44 / 0.21 -> up to 6 words per alignment on average go to the short kernel.
+    // (the long kernel needs >= 8 words in the array)
+    const char *sma = getenv("IPX_SHORT_MAX_AVG");             // tests route either way
+    const long sma_v = sma ? atol(sma) : 0;
+    const uint64_t short_max_avg = (uint64_t)(sma_v >= 1 && sma_v <= 16 ? sma_v : 6);
+    const bool short_reads = b.n_cigar_words <= short_max_avg * b.n_alignments || b.n_cigar_words < 8;
     // short CIGARs: blocks of 128 threads, 2 alignments per thread: a tile's steps (loads, walk, one
     // reservation, copy-out) are a chain of latencies, and eight small tiles in flight per CU hide it
-    // better than four large ones.  The grid is what is resident at once (8 such blocks per CU by
-    // registers), every block loops over tiles: fewer blocks leave CUs idle, more add a ragged last
+    // better than four large ones.  The grid is what is resident at once (10 such blocks per CU by
+    // registers: 88 VGPRs, 5 waves per SIMD), every block loops over tiles: fewer blocks leave CUs idle, more add a ragged last
     // round and more end-of-block atomics on the key masks (measured: 2048 blocks 0.32 ms, 2560 0.42,
     // 8192 0.36, 16384 0.48 on 10 M alignments).
     static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 256 ? 256 : v == 64 ? 64 : 128); }();
@@ -1095,11 +1186,12 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     const uint64_t per_tile = short_reads ? 2ull * short_bt : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
     static const uint64_t max_blocks = [] { const char *e = getenv("IPX_SCAN_BLOCKS"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
-    const uint64_t resident = max_blocks ? max_blocks : (uint64_t)n_cus * (1024u / short_bt);
+    const uint64_t resident = max_blocks ? max_blocks : (uint64_t)n_cus * (1280u / short_bt);
     if (blocks > resident) blocks = resident;
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     ipx_prof_pre(s, IPXK_SCAN);
-    hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail);
+    hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail,
+                       reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_DEFER));
     // stripes pay once many blocks queue on the record counter
     static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
     p.base = n_records_before;
@@ -1107,15 +1199,15 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     if (short_reads && short_bt == 256)
         hipLaunchKernelGGL((k_scan_short<2, 704, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
     else if (short_reads && short_bt == 64)
         hipLaunchKernelGGL((k_scan_short<2, 192, 64>), dim3((uint32_t)blocks), dim3(64), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
     else if (short_reads)
         hipLaunchKernelGGL((k_scan_short<2, 384, 128>), dim3((uint32_t)blocks), dim3(128), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
     else {
         // long CIGARs: waves work through ranges of >= 64 alignments
         static const uint32_t min_range = [] {
@@ -1134,6 +1226,32 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                            b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
     }
+    if (p.n_stripes) {
+        unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
+        hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);
+        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, digs);
+        hipLaunchKernelGGL(k_close_finish, dim3(1), dim3(64), 0, s, counters, p.base, capacity, close_cap);
+    }
+    ipx_prof_mark(s, IPXK_SCAN);
+    return hipGetLastError();
+}
+
+// Second stage of a short-CIGAR scan: the n_defer alignments the first stage listed in defer[] (the caller read
+// the count back with the launch's counters; most launches list none and never get here).
+hipError_t ipx_launch_scan_rest(hipStream_t s, ScanParams p, const ipx_batch &b, const uint32_t *rank_of_tid,
+                                uint4 *items, uint4 *pays, uint8_t *digs, uint64_t capacity, Counters *counters,
+                                uint64_t n_records_before, unsigned long long *close_ws, uint64_t close_cap,
+                                const uint32_t *defer, uint32_t n_defer) {
+    if (n_defer == 0) return hipSuccess;
+    static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(ipx_div_up(n_defer, 256), 2048);
+    p.base = n_records_before;
+    p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
+    const AlnArrays aln{b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar, rank_of_tid,
+                        b.n_alignments, b.n_cigar_words, b.base_read_index};
+    ipx_prof_pre(s, IPXK_SCAN);
+    hipLaunchKernelGGL(k_scan_rest, dim3(blocks), dim3(256), 0, s, p, aln, b.cigar, defer, items, pays, digs, capacity,
+                       counters);
     if (p.n_stripes) {
         unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
         hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);

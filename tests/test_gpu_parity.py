@@ -275,12 +275,15 @@ def test_empty_and_degenerate_inputs():
     ex.close()
 
 
-@pytest.mark.parametrize("ops", [(2, 9), (17, 40), (30, 400)])
+@pytest.mark.parametrize("ops", [(2, 9), (6, 16), (17, 40), (30, 400)])
 @pytest.mark.parametrize("max_indel", [0, 4, 36])
-def test_random_cigars_match_oracle(ops, max_indel):
-    """CIGARs without biological structure through the short-CIGAR kernel (2-9 ops) and the
-    long-CIGAR kernel (more than 16 ops per alignment on average)."""
+def test_random_cigars_match_oracle(ops, max_indel, monkeypatch):
+    """CIGARs without biological structure through the short-CIGAR kernel (2-9 ops; 6-16 ops: most
+    alignments have more than 8 and go through its second stage, k_scan_rest) and the long-CIGAR kernel
+    (more than 16 ops per alignment on average)."""
     n = 6000 if ops[1] < 100 else 1500
+    if ops == (6, 16):
+        monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")      # by default such a batch goes to the long-CIGAR kernel
     batch = helpers.fuzz_batch(n, seed=61 + ops[0], min_ops=ops[0], max_ops=ops[1])
     dev, ora, err = _run_both(batch, ["chrB", "chrA"], {"max_anchor_indel_size": max_indel, "min_anchor_length": 3,
                                                       "min_intron_length": 70})
@@ -368,11 +371,13 @@ def test_striped_append_with_uneven_stripes_and_capacity_retry():
     o.close()
 
 
-def test_short_cigar_tiles_that_overflow_the_record_pool():
-    """Three junctions per alignment: a tile of 512 alignments emits 1536 records, more than the 704 the
-    LDS pool of k_scan_short holds -> the count / reserve / re-run fallback, here together with the
-    striped append (>= 64 blocks) and with a tail of ordinary alignments in the same launch."""
+def test_short_cigar_tiles_that_overflow_the_record_pool(monkeypatch):
+    """Three junctions per alignment: a tile of 256 alignments emits 768 records, more than the 384 the
+    LDS pool of k_scan_short holds -> the tile's alignments are listed and walked by the second stage
+    (k_scan_rest: count / reserve / store), here together with the striped append (>= 64 blocks) and with
+    a tail of ordinary alignments in the same launch."""
     from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")          # 5.6 words per alignment go there anyway; be explicit
     rng = np.random.default_rng(95)
     n = 40_000
     pos = np.sort(rng.integers(1000, 3_000_000, n)).astype(np.int32)
@@ -392,6 +397,49 @@ def test_short_cigar_tiles_that_overflow_the_record_pool():
     helpers.compare_tables(dev, ora)
     dev2, _, _ = _run_both(batch, names, {}, n_push=3)
     helpers.compare_tables(dev2, ora)
+
+
+def test_overflowing_tiles_that_also_hold_long_cigars_are_walked_once(monkeypatch):
+    """A tile can be listed for the second stage twice over: its alignments of more than 8 ops one by one,
+    and -- when its records overflow the pool -- all of it.  Every alignment must still be walked exactly
+    once (counts would double otherwise).  Every fifth alignment here has 11 ops and four junctions, the
+    others 7 ops and three; then one of the long ones gets a bad op (the error must be reported as the oracle's)."""
+    monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")          # 7.8 words per alignment: the long-CIGAR kernel by default
+    rng = np.random.default_rng(97)
+    n = 30_000
+    pos = np.sort(rng.integers(1000, 3_000_000, n)).astype(np.int32)
+    words, offs, ncs = [], [], []
+    total = 0
+    lens = np.array([80, 150, 400, 2500], np.uint32)
+    for i in range(n):
+        k_intr = 4 if i % 5 == 0 else 3
+        w = []
+        for j in range(k_intr):
+            w.append((int(rng.integers(9, 30)) << 4) | 0)
+            w.append((int(lens[rng.integers(0, 4)]) << 4) | 3)
+        w.append((int(rng.integers(9, 30)) << 4) | 0)
+        if i % 5 == 0:
+            w += [(2 << 4) | 2, (12 << 4) | 0]                     # ... D M: 11 ops
+        offs.append(total); ncs.append(len(w)); total += len(w)
+        words.extend(w)
+    batch = {"tid": rng.integers(0, 2, n).astype(np.int32), "pos": pos, "flag": np.zeros(n, np.uint16),
+             "xs": np.zeros(n, np.uint8), "nh": np.ones(n, np.uint8),
+             "cigar_off": np.array(offs, np.uint32), "n_cigar": np.array(ncs, np.uint32),
+             "cigar": np.array(words, np.uint32)}
+    dev, ora, err = _run_both(batch, ["chr1", "chr2"], {})
+    assert err is None and int(ora["counts"].sum()) > 3 * n
+    helpers.compare_tables(dev, ora)
+    dev3, _, _ = _run_both(batch, ["chr1", "chr2"], {}, n_push=3)
+    helpers.compare_tables(dev3, ora)
+    # a bad op in one of the listed alignments: same earliest error as the oracle
+    bad = dict(batch)
+    bad["cigar"] = batch["cigar"].copy()
+    k = 5 * 1234
+    bad["cigar"][offs[k] + 9] = (3 << 4) | 6                       # 'P'
+    dev, _, err = _run_both(bad, ["chr1", "chr2"], {})
+    assert err is not None and err.index == k and err.msg == "Unknown cigar operation 'P'"
+    e = dev["error"]
+    assert e.kind == 1 and e.read_index == k and e.detail == "Unknown cigar operation 'P'"
 
 
 def test_ijunc_by_radix_sort_when_the_bitmap_does_not_apply(monkeypatch):

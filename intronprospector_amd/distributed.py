@@ -190,11 +190,30 @@ class RecordExchanger:
     than the records (bench workload: 8 M histogram bins per 10 M records)."""
 
     N_SAMPLES = 512
+    # Splitters are key-range boundaries; they only decide the load balance, never the result.  A stream of
+    # batches from one input keeps its key distribution, so the splitters of the first batch are kept and
+    # drawn again only after an exchange in which some rank received more than REBALANCE x the mean.
+    REBALANCE = 1.25
 
-    def __init__(self, device, group=None, comm_device=None):
+    def __init__(self, device, group=None, comm_device=None, reuse_splitters=True):
         self.device, self.group = device, group
         # gloo rehearsal on one GPU: collectives on CPU copies
         self.comm_device = comm_device if comm_device is not None else device
+        self.reuse_splitters = reuse_splitters
+        self._splitters = None
+        self.resampled = 0               # how often the splitters were drawn (statistics, tests)
+        self.timed = False               # profiles/rehearse_exchange_timing.py: synchronise and time every stage
+        self.stage_ms = {}
+
+    def _lap(self, name, t0):
+        import time
+        if not self.timed:
+            return t0
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        self.stage_ms[name] = self.stage_ms.get(name, 0.0) + (t1 - t0) * 1e3
+        return t1
 
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
@@ -205,28 +224,41 @@ class RecordExchanger:
         import numpy as np
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
+        import time
+        t0 = time.perf_counter()
         n_local = ex.records_pending()
-        # 1. common splitters from everybody's samples
-        smp = ex.records_sample(self.N_SAMPLES).astype(np.int64)        # ~0 (no records) becomes -1
-        t = torch.from_numpy(smp).to(self.comm_device)
-        bufs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(bufs, t, group=self.group)
-        allk = torch.cat(bufs)
-        allk = torch.sort(allk[allk >= 0]).values
-        if allk.numel():
-            q = (torch.arange(1, world, device=allk.device) * allk.numel()) // world
-            splitters = allk[q].cpu().numpy().astype(np.uint64)
-        else:
-            splitters = np.full(world - 1, np.iinfo(np.int64).max, np.uint64)
+        # 1. common splitters from everybody's samples (kept from the previous run while that stayed balanced;
+        #    every rank sees the same counts matrix, so all ranks decide alike)
+        if self._splitters is None or not self.reuse_splitters or len(self._splitters) != world - 1:
+            smp = ex.records_sample(self.N_SAMPLES).astype(np.int64)        # ~0 (no records) becomes -1
+            t = torch.from_numpy(smp).to(self.comm_device)
+            bufs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(bufs, t, group=self.group)
+            allk = torch.cat(bufs)
+            allk = torch.sort(allk[allk >= 0]).values
+            if allk.numel():
+                q = (torch.arange(1, world, device=allk.device) * allk.numel()) // world
+                self._splitters = allk[q].cpu().numpy().astype(np.uint64)
+            else:
+                self._splitters = np.full(world - 1, np.iinfo(np.int64).max, np.uint64)
+            self.resampled += 1
+        splitters = self._splitters
+        t0 = self._lap("splitters", t0)
         # 2. partition my records by key range
         send = torch.empty(max(n_local, 1) * 32, dtype=torch.uint8, device=self.device)
         counts = ex.records_partition(splitters, send.data_ptr())
+        t0 = self._lap("partition", t0)
         # 3. who sends how much to whom, then the exchange itself
         c = torch.from_numpy(counts.astype(np.int64)).to(self.comm_device)
         cm = [torch.empty_like(c) for _ in range(world)]
         dist.all_gather(cm, c, group=self.group)
-        recv_counts = torch.stack(cm)[:, rank].cpu().tolist()          # one read-back, not one per rank
+        cmat = torch.stack(cm).cpu()                                   # one read-back, not one per rank
+        recv_counts = cmat[:, rank].tolist()
         n_recv = sum(recv_counts)
+        per_rank = cmat.sum(dim=0).to(torch.float64)                   # records each rank receives
+        if world > 1 and float(per_rank.max()) > self.REBALANCE * max(float(per_rank.mean()), 1.0):
+            self._splitters = None                                     # draw new splitters next time
+        t0 = self._lap("counts", t0)
         send_c = self._to_comm(send[:n_local * 32])
         recv_c = torch.empty(max(n_recv, 1) * 32, dtype=torch.uint8, device=self.comm_device)
         dist.all_to_all_single(recv_c[:n_recv * 32], send_c, output_split_sizes=[x * 32 for x in recv_counts],
@@ -234,19 +266,33 @@ class RecordExchanger:
         recv = recv_c if recv_c.device == self.device else recv_c.to(self.device)
         if recv.device.type == "cuda":
             torch.cuda.synchronize(recv.device)
+        t0 = self._lap("all_to_all", t0)
         # 4. the key range is now local: ordinary finalize
         ex.records_adopt(n_recv, recv.data_ptr(), n_alignments_local)
+        t0 = self._lap("adopt", t0)
         rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
         if rc:
             ex._check(rc)
+        t0 = self._lap("finalize", t0)
         # 5. sjN numbering is global: rank of the creation order over all ranks' junctions
         n = int(table.n_junctions)
         co = torch.empty(n, dtype=torch.int64, device=self.device)
         if n:
             ex._check(ex.lib.ipx_copy(ex.h, co.data_ptr(), table.creator_order, n * 8))
-        parts = _all_gather_var(self._to_comm(co), self.group)
-        all_co = torch.sort(torch.cat(parts)).values
-        ijunc = torch.searchsorted(all_co, self._to_comm(co))
+        # the local ijunc is the rank inside this table: scattering by it sorts the orders without a sort; the
+        # global rank is the number of smaller orders in every rank's (sorted) list
+        lij = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            ex._check(ex.lib.ipx_copy(ex.h, lij.data_ptr(), table.ijunc, n * 4))
+        co_sorted = torch.empty_like(co)
+        co_sorted[lij.to(torch.int64)] = co
+        co_c = self._to_comm(co)
+        parts = _all_gather_var(self._to_comm(co_sorted), self.group)
+        ijunc = torch.zeros(n, dtype=torch.int64, device=co_c.device)
+        for part in parts:
+            if part.numel():
+                ijunc += torch.searchsorted(part, co_c)
+        t0 = self._lap("global_ijunc", t0)
         self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
         return table, ijunc
 

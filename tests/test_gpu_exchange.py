@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, genome, q):
+def _worker(rank, world, port, genome, reuse, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,22 +40,25 @@ def _worker(rank, world, port, genome, q):
             gen2 = (gen.names, [(t, m, len(s)) for (t, m), s in zip(gen.twobit(), gen.seqs)])
         else:
             batch, names, _ = synth.short_reads(60_000, seed=42, n_targets=4, target_len=2_800_000, n_sites=700)
-        n = len(batch["tid"])
-        cuts = np.linspace(0, n, world + 1).astype(int)
-        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
         ex = ipa.JunctionsExtractor(targets=names, genome=gen2, **params)
-        ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
         xch = RecordExchanger(torch.device("cuda", 0), comm_device=torch.device("cpu"))
-        table, ijunc = xch.run(ex, hi - lo)
-        t = table_to_torch(ex, table, "cpu")
-        t["ijunc"] = ijunc.cpu()
-        # gather every rank's rows (rank order = key order)
-        gathered = {k: torch.cat(_all_gather_var(t[k])) for k in
-                    ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc", "counts",
-                     "hist_value", "hist_count")}
-        nper = _all_gather_var(torch.tensor([t["target"].shape[0]]))
-        ex.close()
-        if rank == 0:
+
+        def one_exchange(batch):
+            n = len(batch["tid"])
+            cuts = np.linspace(0, n, world + 1).astype(int)
+            lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+            ex.clear()
+            ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
+            table, ijunc = xch.run(ex, hi - lo)
+            t = table_to_torch(ex, table, "cpu")
+            t["ijunc"] = ijunc.cpu()
+            # gather every rank's rows (rank order = key order)
+            gathered = {k: torch.cat(_all_gather_var(t[k])) for k in
+                        ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc", "counts",
+                         "hist_value", "hist_count")}
+            nper = _all_gather_var(torch.tensor([t["target"].shape[0]]))
+            if rank != 0:
+                return None
             ora = Oracle(targets=names, genome_fasta=fasta, **params)
             ora.process(batch)
             ref = ora.table()
@@ -74,7 +77,27 @@ def _worker(rank, world, port, genome, q):
                 got = np.repeat(gathered["hist_value"].numpy(), gathered["hist_count"].numpy())
                 if not np.array_equal(flat.astype(np.int64), got.astype(np.int64)):
                     bad.append("offsets")
-            q.put((bad, len(oo), [int(x.item()) for x in nper]))
+            return bad, len(oo), [int(x.item()) for x in nper]
+
+        out = one_exchange(batch)
+        if reuse:
+            # a second batch of the same kind keeps the splitters; one that sits on a single target upsets the
+            # balance (still exact), so the run after it draws new ones
+            drawn = [xch.resampled]
+            b2, _, _ = synth.short_reads(50_000, seed=43, n_targets=4, target_len=2_800_000, n_sites=700)
+            r2 = one_exchange(b2)
+            drawn.append(xch.resampled)
+            keep = np.nonzero(b2["tid"] == 0)[0]
+            b3 = synth.concat_batches([synth.slice_batch(b2, int(i), int(i) + 1) for i in keep[:4000]])
+            r3 = one_exchange(b3)
+            drawn.append(xch.resampled)
+            r4 = one_exchange(b3)
+            drawn.append(xch.resampled)
+            if rank == 0:
+                out = (out[0] + r2[0] + r3[0] + r4[0], out[1], out[2], drawn, r4[2])
+        ex.close()
+        if rank == 0:
+            q.put(out)
     finally:
         dist.destroy_process_group()
 
@@ -82,6 +105,15 @@ def _worker(rank, world, port, genome, q):
 @pytest.mark.parametrize("genome", [False, True])
 def test_record_exchange_two_ranks_equals_single_run(genome, oracle_lib):
     from tests.mp_util import run_workers
-    bad, n, nper = run_workers(_worker, 2, (_free_port(), genome), timeout=300)
+    bad, n, nper = run_workers(_worker, 2, (_free_port(), genome, False), timeout=300)
     assert not bad, "exchanged tables differ from the single run in: %s" % bad
     assert n > 100 and min(nper) > 0, nper       # both ranks own part of the key space
+
+
+def test_record_exchange_keeps_its_splitters_while_balanced(oracle_lib):
+    from tests.mp_util import run_workers
+    bad, n, nper, drawn, nper_last = run_workers(_worker, 2, (_free_port(), False, True), timeout=300)
+    assert not bad, "exchanged tables differ from the single run in: %s" % bad
+    # drawn once for the first batch, kept for the second and (still) for the skewed third, drawn again for the fourth
+    assert drawn == [1, 1, 1, 2], drawn
+    assert min(nper_last) > 0, nper_last

@@ -658,7 +658,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         // the per-chunk head counts of the reduce
         const uint64_t chunks = ipx_reduce_chunks(R);
         const uint64_t chunks_al = (chunks + 63) & ~63ull;
-        const uint64_t sums1 = ipx_div_up(chunks, 4096) + 2;
+        const uint64_t sums1 = ipx_scan_sums_words(chunks, chunks);
         const size_t ws_bytes = std::max(ipx_sort_workspace_bytes(R),
                                          (size_t)((2 * chunks_al + sums1) * sizeof(uint32_t) + 1024));
         // one pass per (up to) 8 bits on which the keys differ (OR ^ AND).  The digit bytes that came
@@ -672,6 +672,13 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         const bool use_bytes = bytes_ok && with_bytes.n <= ideal.n;
         const SortPlan plan = use_bytes ? with_bytes : ideal;
         h->first_hint = ideal.digits[0];
+        if (getenv("IPX_DEBUG_PLAN")) {                      // the sort plan, for the curious
+            fprintf(stderr, "ipx: %llu records, key bits %u, vary %08x %08x %08x, %u passes%s:", (unsigned long long)R,
+                    h->key.total_bits, vary[2], vary[1], vary[0], plan.n, use_bytes ? " (first from the digit bytes)" : "");
+            for (uint32_t k = 0; k < plan.n; ++k)
+                fprintf(stderr, " [%u+%u,%u+%u]", plan.digits[k].lo1, plan.digits[k].w1, plan.digits[k].lo2, plan.digits[k].w2);
+            fprintf(stderr, "\n");
+        }
         if (resort) {
             if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
             if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
@@ -694,8 +701,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         uint32_t *tot = h->d_small.as<uint32_t>();
         if (resort) {
             HIPCHK(ipx_launch_count_heads(s, si, chunk_j, chunk_b));
-            HIPCHK(ipx_launch_scan_u32(s, chunk_j, chunk_j, chunks, sums, tot + 0));
-            HIPCHK(ipx_launch_scan_u32(s, chunk_b, chunk_b, chunks, sums, tot + 1));
+            HIPCHK(ipx_launch_scan_u32_pair(s, chunk_j, chunk_j, chunks, tot + 0, chunk_b, chunk_b, chunks, tot + 1, sums));
         }
         if ((rc = read_back(h, small, tot, 2))) return rc;
         h->prof.collect();
@@ -716,7 +722,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             rb.counts = tmp.take<unsigned long long>(3ull * J);
             rb.bin_off = tmp.take<uint32_t>(B); rb.bin_count = tmp.take<uint32_t>(B);
             rb.bin_flag = tmp.take<uint32_t>(B); rb.bin_pos = tmp.take<uint32_t>(B);
-            rb.scan_sums = tmp.take<uint32_t>(ipx_div_up(std::max<uint64_t>(std::max(J, B), 1), 4096) + 2);
+            rb.scan_sums = tmp.take<uint32_t>(ipx_scan_sums_words(J, B));
             rb.totals = tmp.take<uint32_t>(64);
             rb.rank_a = tmp.take<uint4>(J); rb.rank_b = tmp.take<uint4>(J);
             detail4 = tmp.take<uint32_t>(64);

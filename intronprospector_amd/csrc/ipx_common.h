@@ -232,6 +232,11 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
 // in == out allowed; block_sums needs div_up(n,4096)+1 words; total may be NULL
 hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
                                uint32_t *block_sums, uint32_t *total);
+// two independent arrays in the same three launches (n2 == 0: one); block_sums: ipx_scan_sums_words(n1, n2) words
+size_t ipx_scan_sums_words(uint64_t n1, uint64_t n2);
+hipError_t ipx_launch_scan_u32_pair(hipStream_t s, const uint32_t *in1, uint32_t *out1, uint64_t n1, uint32_t *total1,
+                                    const uint32_t *in2, uint32_t *out2, uint64_t n2, uint32_t *total2,
+                                    uint32_t *block_sums);
 
 // ipx_exchange.hip: key-range partitioning of the pending records for the multi-GPU exchange
 hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,

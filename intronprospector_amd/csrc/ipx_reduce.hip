@@ -684,8 +684,8 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_flag);
     ipx_prof_mark(s, IPXK_BINS);
     // compaction offsets: junctions, bins, bins per junction
-    if ((e = ipx_launch_scan_u32(s, rb.jvalid, rb.jpos, J, rb.scan_sums, rb.totals + 0)) != hipSuccess) return e;
-    if ((e = ipx_launch_scan_u32(s, rb.bin_flag, rb.bin_pos, B, rb.scan_sums, rb.totals + 1)) != hipSuccess) return e;
+    if ((e = ipx_launch_scan_u32_pair(s, rb.jvalid, rb.jpos, J, rb.totals + 0, rb.bin_flag, rb.bin_pos, B, rb.totals + 1,
+                                      rb.scan_sums)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
                        rb.bin_pos, rb.out_hist_value, rb.out_hist_count);
     ipx_prof_mark(s, IPXK_EMIT_BINS);

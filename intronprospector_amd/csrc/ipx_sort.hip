@@ -299,65 +299,93 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *to
     return off + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t *__restrict__ in, uint64_t n,
-                                                   uint32_t *__restrict__ sums) {
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+// One launch serves one or two independent arrays (blocks [0, a.m) work on job a, the rest on job b): the
+// scans of a step are small and latency-bound, so two arrays in three launches instead of six.
+struct ScanJob {
+    const uint32_t *in;
+    uint32_t *out;
+    uint64_t n;
+    uint32_t *sums;      // one word per SCAN_TILE elements
+    uint32_t *total;     // may be null
+    uint32_t m;          // tiles = blocks
+};
+
+__global__ __launch_bounds__(256) void k_scan_sums(ScanJob a, ScanJob b) {
+    const bool first = blockIdx.x < a.m;
+    const ScanJob &j = first ? a : b;
+    const uint32_t blk = first ? blockIdx.x : blockIdx.x - a.m;
+    const uint64_t base = (uint64_t)blk * SCAN_TILE + (uint64_t)threadIdx.x * 16;
     uint32_t s = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k)
-        if (base + k < n) s += in[base + k];
+        if (base + k < j.n) s += j.in[base + k];
     uint32_t tot;
     (void)block_excl_scan_256(s, &tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0) j.sums[blk] = tot;
 }
 
-__global__ __launch_bounds__(256) void k_scan_top(uint32_t *sums, uint64_t m, uint32_t *total) {
+// block 0: job a, block 1: job b
+__global__ __launch_bounds__(256) void k_scan_top(ScanJob a, ScanJob b) {
+    const ScanJob &j = blockIdx.x == 0 ? a : b;
     uint32_t carry = 0;
-    for (uint64_t base = 0; base < m; base += 256) {
+    for (uint64_t base = 0; base < j.m; base += 256) {
         const uint64_t i = base + threadIdx.x;
-        const uint32_t v = (i < m) ? sums[i] : 0;
+        const uint32_t v = (i < j.m) ? j.sums[i] : 0;
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256(v, &tot);
-        if (i < m) sums[i] = carry + ex;
+        if (i < j.m) j.sums[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0 && total) *total = carry;
+    if (threadIdx.x == 0 && j.total) *j.total = carry;
 }
 
 // in == out is allowed (each thread reads its 16 values before it writes them)
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint32_t *out, uint64_t n,
-                                                    const uint32_t *__restrict__ sums) {
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+__global__ __launch_bounds__(256) void k_scan_apply(ScanJob a, ScanJob b) {
+    const bool first = blockIdx.x < a.m;
+    const ScanJob &j = first ? a : b;
+    const uint32_t blk = first ? blockIdx.x : blockIdx.x - a.m;
+    const uint64_t base = (uint64_t)blk * SCAN_TILE + (uint64_t)threadIdx.x * 16;
     uint32_t v[16];
     uint32_t s = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
+        v[k] = (base + k < j.n) ? j.in[base + k] : 0;
         s += v[k];
     }
     uint32_t tot;
-    uint32_t ex = block_excl_scan_256(s, &tot) + sums[blockIdx.x];
+    uint32_t ex = block_excl_scan_256(s, &tot) + j.sums[blk];
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
-        if (base + k < n) out[base + k] = ex;
+        if (base + k < j.n) j.out[base + k] = ex;
         ex += v[k];
     }
 }
 
 }  // namespace
 
-hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
-                               uint32_t *block_sums, uint32_t *total) {
-    if (n == 0) {
-        if (total) return hipMemsetAsync(total, 0, sizeof(uint32_t), s);
-        return hipSuccess;
-    }
-    const uint64_t m = ipx_div_up(n, SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_sums, dim3((uint32_t)m), dim3(256), 0, s, in, n, block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, m, total);
-    hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)m), dim3(256), 0, s, in, out, n, block_sums);
+// Exclusive scans of one or two arrays (n2 == 0: one).  block_sums: ipx_scan_sums_words(n1, n2) words.
+size_t ipx_scan_sums_words(uint64_t n1, uint64_t n2) { return (size_t)(ipx_div_up(n1, SCAN_TILE) + ipx_div_up(n2, SCAN_TILE) + 4); }
+
+hipError_t ipx_launch_scan_u32_pair(hipStream_t s, const uint32_t *in1, uint32_t *out1, uint64_t n1, uint32_t *total1,
+                                    const uint32_t *in2, uint32_t *out2, uint64_t n2, uint32_t *total2,
+                                    uint32_t *block_sums) {
+    // an empty array only has its total to report
+    if (n1 == 0 && total1) { hipError_t e = hipMemsetAsync(total1, 0, sizeof(uint32_t), s); if (e != hipSuccess) return e; }
+    if (n2 == 0 && total2) { hipError_t e = hipMemsetAsync(total2, 0, sizeof(uint32_t), s); if (e != hipSuccess) return e; }
+    ScanJob a{in1, out1, n1, block_sums, total1, (uint32_t)ipx_div_up(n1, SCAN_TILE)};
+    ScanJob b{in2, out2, n2, block_sums + a.m + 2, total2, (uint32_t)ipx_div_up(n2, SCAN_TILE)};
+    if (a.m == 0) { a = b; b.m = 0; b.n = 0; }
+    if (a.m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_sums, dim3(a.m + b.m), dim3(256), 0, s, a, b);
+    hipLaunchKernelGGL(k_scan_top, dim3(b.m ? 2 : 1), dim3(256), 0, s, a, b);
+    hipLaunchKernelGGL(k_scan_apply, dim3(a.m + b.m), dim3(256), 0, s, a, b);
     ipx_prof_mark(s, IPXK_SCAN_U32);
     return hipGetLastError();
+}
+
+hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
+                               uint32_t *block_sums, uint32_t *total) {
+    return ipx_launch_scan_u32_pair(s, in, out, n, total, nullptr, nullptr, 0, nullptr, block_sums);
 }
 
 // workspace: hist[256 * n_tiles] + bin_total[256]

@@ -431,6 +431,14 @@ def test_overflowing_tiles_that_also_hold_long_cigars_are_walked_once(monkeypatc
     helpers.compare_tables(dev, ora)
     dev3, _, _ = _run_both(batch, ["chr1", "chr2"], {}, n_push=3)
     helpers.compare_tables(dev3, ora)
+    # room for 1000 records only: the first stage fits (it stores next to nothing here), the second does not ->
+    # the record arrays grow and both stages run again
+    ex = _extractor(targets=["chr1", "chr2"])
+    ex.reserve(0, 0, 1000)
+    ex.push(batch)
+    small = ex.get_junctions()
+    ex.close()
+    helpers.compare_tables(small, ora)
     # a bad op in one of the listed alignments: same earliest error as the oracle
     bad = dict(batch)
     bad["cigar"] = batch["cigar"].copy()

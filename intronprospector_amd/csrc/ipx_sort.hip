@@ -176,6 +176,16 @@ __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, u
     const uint64_t base = (uint64_t)tile_id * TILE;
     const uint32_t valid = (uint32_t)((n - base) < TILE ? (n - base) : TILE);
 
+    // wave w owns tile items [w*PER_WAVE, (w+1)*PER_WAVE) in IPT rounds of 64: item order is
+    // (wave, round, lane), which is memory order -> the split is stable.  The loads go out first: the
+    // bin bases below (two dependent loads, a scan, a barrier) are computed while they are under way.
+    uint4 it[IPT];
+#pragma unroll
+    for (uint32_t r = 0; r < IPT; ++r) {
+        const uint32_t li = wave * PER_WAVE + r * 64 + lane;
+        if (li < valid) it[r] = src[base + li];
+    }
+
     for (uint32_t k = t; k < NW * 256 / 2; k += NT) reinterpret_cast<uint32_t *>(&cnt[0][0])[k] = 0;
     // global base of bin t = (items in smaller bins) + (bin-t items in earlier tiles); threads 0..255
     uint32_t my_total = 0, my_before = 0, incl2 = 0;
@@ -197,16 +207,12 @@ __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, u
         gbase[t] = off + incl2 - my_total + my_before;
     }
 
-    // wave w owns tile items [w*PER_WAVE, (w+1)*PER_WAVE) in IPT rounds of 64: item order is
-    // (wave, round, lane), which is memory order -> the split is stable.
-    uint4 it[IPT];
     uint32_t rk[IPT];                          // rank among equal digits inside the wave's chunk
     uint32_t dg[IPT];
 #pragma unroll
     for (uint32_t r = 0; r < IPT; ++r) {
         const uint32_t li = wave * PER_WAVE + r * 64 + lane;
         const bool ok = li < valid;
-        if (ok) it[r] = src[base + li];
         const uint32_t dig = ok ? digit_of(it[r], d) : 0xffffffffu;
         dg[r] = dig;
         // lanes with the same digit (invalid lanes match nobody valid)

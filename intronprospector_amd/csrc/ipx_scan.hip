@@ -656,9 +656,15 @@ __device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArra
     c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = a.base_read_index + i;
     nc = 0; off = 0;
     if (i < a.n) {
+        // all seven fields at once (one round trip; fetching pos, off, nh and xs only for alignments that pass
+        // the gate made it two), then the target's rank
         const int32_t tid = a.tid[i];
         c.flag = a.flag[i];
         nc = a.nc[i];
+        const int32_t pos = a.pos[i];
+        const uint32_t off_in = a.off[i];
+        const uint32_t nh = a.nh[i];
+        const uint32_t xs = a.xs[i];
         // junctions_extractor.cc:536
         if (nc <= 1 || tid < 0 || (c.flag & (F_QCFAIL | F_DUP))) nc = 0;
         if (nc) {
@@ -667,16 +673,15 @@ __device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArra
                 err = e < err ? e : err;
                 nc = 0;
             } else {
-                c.pos = a.pos[i];
-                off = a.off[i];
+                c.pos = pos;
+                off = off_in;
                 if ((uint64_t)off + nc > a.n_words) {          // words outside the batch: never dereferenced
                     const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
                     err = e < err ? e : err;
                     nc = 0;
                 }
-                c.nhc = a.nh[i];
+                c.nhc = nh;
                 c.rank = a.rank_of_tid[tid];
-                const uint32_t xs = a.xs[i];
                 c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
                                                             : (xs ? xs : (uint32_t)'.');
             }

@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: [0.0, 0])
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][-40:]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
             agg[(k, r["Counter_Name"])][0] += float(r["Counter_Value"])
             agg[(k, r["Counter_Name"])][1] += 1
 ks = sorted({k for k, _ in agg})

@@ -42,12 +42,14 @@ __device__ __forceinline__ Heads load_heads(const uint4 *__restrict__ items, uin
                                             uint32_t lane) {
     Heads h;
     h.ok = i < n;
+    // the item and its predecessor as two independent loads (the second hits the lines of the first): taking the
+    // predecessor from the lane below and letting lane 0 fetch its own afterwards put two load latencies in a row
+    const bool has_prev = h.ok && i > 0;
+    const uint4 *pp = items + (has_prev ? i - 1 : 0);
     h.it = h.ok ? items[i] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    uint32_t px = __shfl_up(h.it.x, 1), py = __shfl_up(h.it.y, 1), pz = __shfl_up(h.it.z, 1);
-    if (lane == 0 && h.ok && i > 0) {
-        const uint4 p = items[i - 1];
-        px = p.x; py = p.y; pz = p.z;
-    }
+    const uint4 p = has_prev ? *pp : make_uint4(0, 0, 0, 0);
+    const uint32_t px = p.x, py = p.y, pz = p.z;
+    (void)lane;
     const bool first = (i == 0);
     const bool dj = ((px >> 16) != (h.it.x >> 16)) || (py != h.it.y) || (pz != h.it.z);
     const bool db = dj || ((px & 0xffffu) != (h.it.x & 0xffffu));

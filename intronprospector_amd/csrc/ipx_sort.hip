@@ -410,10 +410,11 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
                            size_t workspace_bytes, int prof_all) {
     if (n == 0 || plan.n == 0) return hipSuccess;
     if (ipx_sort_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
-    // large inputs: 4096-item tiles moved by 1024 threads (IPX_SORT_TILE=2048 keeps the small tile)
+    // large inputs (3 M records on: L with 4.05 M gains 1.5 % of its step, hist and bin scan get cheaper): 4096-item
+    // tiles moved by 1024 threads (IPX_SORT_TILE=2048 keeps the small tile)
     const char *tile_e = getenv("IPX_SORT_TILE");               // tests force either tile size
     const uint32_t tile_env = tile_e ? (uint32_t)atoi(tile_e) : 0u;
-    const bool big = tile_env ? tile_env == 4096 : n >= (4u << 20);
+    const bool big = tile_env ? tile_env == 4096 : n >= (3u << 20);
     const uint32_t tile_items = big ? 4096u : SORT_TILE;
     const uint32_t n_tiles = (uint32_t)ipx_div_up(n, tile_items);
     uint32_t *hist = (uint32_t *)workspace;

@@ -468,7 +468,7 @@ def test_ijunc_by_radix_sort_when_the_bitmap_does_not_apply(monkeypatch):
 @pytest.mark.parametrize("tile", ["2048", "4096"])
 def test_both_sort_tile_sizes_on_small_and_ragged_inputs(monkeypatch, tile):
     """The radix passes move 2048-item tiles (512 threads) on small inputs and 4096-item tiles (1024
-    threads) from 4 M records on; IPX_SORT_TILE forces either one, here on record counts that are not a
+    threads) from 3 M records on; IPX_SORT_TILE forces either one, here on record counts that are not a
     multiple of the tile and on one that is smaller than a tile."""
     from intronprospector_amd import synth
     monkeypatch.setenv("IPX_SORT_TILE", tile)

@@ -22,9 +22,10 @@ class BgzfReader {
 public:
     // does the file start with a BGZF block header?
     static bool is_bgzf(const std::string &path);
-    // n_threads 0: IPX_DECODE_THREADS from the environment, else min(hardware threads, 8): beyond that
-    // the single consumer that parses the records is the limit (measured)
+    // n_threads 0: IPX_DECODE_THREADS from the environment, else default_threads()
     explicit BgzfReader(const std::string &path, unsigned n_threads = 0);
+    // three quarters of the CPUs this process may use (cgroup quota respected), at most 12 (measured)
+    static unsigned default_threads();
     ~BgzfReader();
     BgzfReader(const BgzfReader &) = delete;
     BgzfReader &operator=(const BgzfReader &) = delete;

@@ -15,6 +15,8 @@
 //       strand tags set on every record the way update_strand_tag does
 //   ipx_host_check bench-decode FILE [THREADS]
 //       decodes every record; prints records, seconds, records/s and compressed MB/s
+//   ipx_host_check bench-inflate FILE [THREADS]
+//       BGZF inflate only (no record parsing)
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +24,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "aln_reader.hh"
 #include "gz_ostream.hh"
@@ -190,6 +193,23 @@ static int bench_decode(const char *path, const char *threads) {
     return 0;
 }
 
+// inflate only: what the BGZF stage delivers when nobody parses the records
+static int bench_inflate(const char *path, const char *threads) {
+    const unsigned nt = threads ? (unsigned)atoi(threads) : 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    BgzfReader rd(path, nt);
+    std::vector<uint8_t> buf(1 << 20);
+    uint64_t bytes = 0, sum = 0;
+    for (size_t got; (got = rd.read(buf.data(), buf.size())) != 0;) {
+        bytes += got;
+        sum += buf[0] + buf[got - 1];
+    }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("{\"inflated_MB\": %.1f, \"seconds\": %.4f, \"inflated_MB_per_s\": %.1f, \"compressed_MB_per_s\": %.1f, \"threads\": %u, "
+           "\"checksum\": %llu}\n", bytes / 1e6, s, bytes / 1e6 / s, rd.compressed_bytes() / 1e6 / s, rd.threads(), (unsigned long long)sum);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
         if (argc == 3 && std::string(argv[1]) == "dump-aln") return dump_aln(argv[2]);
@@ -197,10 +217,11 @@ int main(int argc, char **argv) {
         if (argc >= 4 && std::string(argv[1]) == "copy-aln") return copy_aln(argc, argv);
         if (argc == 4 && std::string(argv[1]) == "make-bam") return make_bam(strtoull(argv[2], nullptr, 10), argv[3]);
         if ((argc == 3 || argc == 4) && std::string(argv[1]) == "bench-decode") return bench_decode(argv[2], argc == 4 ? argv[3] : nullptr);
+        if ((argc == 3 || argc == 4) && std::string(argv[1]) == "bench-inflate") return bench_inflate(argv[2], argc == 4 ? argv[3] : nullptr);
     } catch (const std::exception &e) {
         fprintf(stderr, "Error: %s\n", e.what());
         return 1;
     }
-    fprintf(stderr, "usage: ipx_host_check dump-aln FILE | print-table PREFIX MIN_CONF < table.txt | make-bam N OUT | bench-decode FILE [THREADS]\n");
+    fprintf(stderr, "usage: ipx_host_check dump-aln FILE | print-table PREFIX MIN_CONF < table.txt | make-bam N OUT | bench-decode FILE [THREADS] | bench-inflate FILE [THREADS]\n");
     return 2;
 }

@@ -150,13 +150,7 @@ __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx 
 // The reference's ReadJunctionExtractor::parse_read over one CIGAR.  EMIT=false counts
 // the records that pass junction_qc (and reports a CIGAR error); EMIT=true stores them
 // at slot0, slot0+1, ...  Returns the number of QC-passed records.
-struct Pool {                    // LDS staging of a tile's records (k_scan_pool)
-    uint4 *item, *pay;
-    uint32_t *n;
-    uint32_t cap;
-};
-
-// MODE 0: count; MODE 1: store at slot0 + ordinal of the stripe; MODE 2: append to the LDS pool;
+// MODE 0: count; MODE 1: store at slot0 + ordinal of the stripe;
 // MODE 3: records with ordinal >= slot0 each reserve their own slot of the stripe (k_scan_long's rare re-run)
 template <int MODE>
 __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx &c,
@@ -164,7 +158,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
                                              uint64_t slot0, uint64_t capacity,
                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
                                              uint8_t *__restrict__ digs, KeyBits &kb,
-                                             unsigned long long &err, const Pool *pool = nullptr,
+                                             unsigned long long &err,
                                              unsigned long long *n_records = nullptr, uint32_t stripe = 0) {
     uint32_t state = ST_LIMBO;
     int64_t target_pos = c.pos, anchor_start = -1, intron_start = -1, intron_end = -1, anchor_end = -1;
@@ -180,13 +174,6 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
                 if (ordinal >= slot0 && ordinal <= IPX_ORD_MAX_ORDINAL) {
                     const uint64_t idx = append_index(p, stripe, atomicAdd(n_records, 1ull));
                     if (idx < capacity) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
-                }
-            } else if (MODE == 2) {
-                const uint32_t slot = atomicAdd(pool->n, 1u);
-                if (slot < pool->cap && ordinal <= IPX_ORD_MAX_ORDINAL) {
-                    uint8_t dummy_dig;
-                    KeyBits dummy_kb;
-                    store_record(p, c, r, ordinal, 0, pool->item + slot, pool->pay + slot, &dummy_dig, dummy_kb);
                 }
             }
             ++ordinal;
@@ -505,7 +492,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
                 c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
                 c.read_index = base_read_index + my_i;
                 (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, digs, kb,
-                                  my_err, nullptr, append_counter(counters, p, stripe), stripe);
+                                  my_err, append_counter(counters, p, stripe), stripe);
                 redo = false;
             }
         }
@@ -1031,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, co
         if (cn) {
             unsigned long long dummy = IPX_ERRW_NONE;
             (void)run_read<1>(p, c, cigar + off, nc, slot + (incl - cn), capacity, items, pays, digs, kb, dummy,
-                              nullptr, nullptr, stripe);
+                              nullptr, stripe);
         }
     }
     unsigned long long e = my_err;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
         const uint32_t op = w & 0xfu, len = w >> 4;
         // BAM_CIGAR_STR "MIDNSHP=XB": M0 I1 D2 N3 S4 H5 P6 =7 X8 B9; classes 1 = M/=/X, 2 = N, 4 = I/D, 8 = S/H
         const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
-        const bool c_m = run && (cls & 1u), c_n = run && (cls & 2u), c_id = run && (cls & 4u), c_sh = run && (cls & 8u);
+        const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
         const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
         // I/D :257-275: counters first, then the test
         lind += (c_id && in_l) ? len : 0u;
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 const bool run = active && left != 0;
                 const uint32_t op = w & 0xfu, len = w >> 4;
                 const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
-                const bool c_m = run && (cls & 1u), c_n = run && (cls & 2u), c_id = run && (cls & 4u), c_sh = run && (cls & 8u);
+                const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
                 const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
                 lind += (c_id && in_l) ? len : 0u;
                 rind += (c_id && in_r) ? len : 0u;

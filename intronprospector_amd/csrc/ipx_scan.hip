@@ -1163,13 +1163,14 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     const long sma_v = sma ? atol(sma) : 0;
     const uint64_t short_max_avg = (uint64_t)(sma_v >= 1 && sma_v <= 16 ? sma_v : 6);
     const bool short_reads = b.n_cigar_words <= short_max_avg * b.n_alignments || b.n_cigar_words < 8;
-    // short CIGARs: blocks of 128 threads, 2 alignments per thread: a tile's steps (loads, walk, one
-    // reservation, copy-out) are a chain of latencies, and eight small tiles in flight per CU hide it
-    // better than four large ones.  The grid is what is resident at once (10 such blocks per CU by
-    // registers: 88 VGPRs, 5 waves per SIMD), every block loops over tiles: fewer blocks leave CUs idle, more add a ragged last
-    // round and more end-of-block atomics on the key masks (measured: 2048 blocks 0.32 ms, 2560 0.42,
-    // 8192 0.36, 16384 0.48 on 10 M alignments).
-    static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 256 ? 256 : v == 64 ? 64 : 128); }();
+    // short CIGARs: blocks of 256 threads, 2 alignments per thread (tile = 512 alignments, pool of 768 records).
+    // With 4 waves per SIMD the 128-thread block won (more tiles in flight hide a tile's chain of latencies:
+    // loads, walk, one reservation, copy-out); at 5 waves per SIMD the kernel is as much instruction- as
+    // latency-bound and the larger tile packs the alignments that need the walk into fuller waves (a third of
+    // S's alignments: 85 of 256 fill 1.3 waves, 170 of 512 fill 2.7): 0.287 -> 0.263 ms.  The grid is what is
+    // resident at once (96 VGPRs, 5 waves per SIMD), every block loops over tiles: fewer blocks leave CUs idle,
+    // more add a ragged last round and more end-of-block atomics on the key masks.
+    static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 128 ? 128 : v == 64 ? 64 : 256); }();
     static const uint32_t n_cus = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -1189,7 +1190,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     p.base = n_records_before;
     p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
     if (short_reads && short_bt == 256)
-        hipLaunchKernelGGL((k_scan_short<2, 704, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
+        hipLaunchKernelGGL((k_scan_short<2, 768, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
     else if (short_reads && short_bt == 64)

@@ -372,7 +372,7 @@ def test_striped_append_with_uneven_stripes_and_capacity_retry():
 
 
 def test_short_cigar_tiles_that_overflow_the_record_pool(monkeypatch):
-    """Three junctions per alignment: a tile of 256 alignments emits 768 records, more than the 384 the
+    """Three junctions per alignment: a tile of 512 alignments emits 1536 records, more than the 768 the
     LDS pool of k_scan_short holds -> the tile's alignments are listed and walked by the second stage
     (k_scan_rest: count / reserve / store), here together with the striped append (>= 64 blocks) and with
     a tail of ordinary alignments in the same launch."""

@@ -114,6 +114,14 @@ def test_bgzf_blocks_inflate_in_parallel_in_file_order(host_check, tmp_path):
     r = subprocess.run([host_check, "bench-decode", bam, "4"], stdout=subprocess.PIPE, check=True)
     rep = json.loads(r.stdout)
     assert rep["records"] == 60000 and rep["cigar_words"] == 180000 and rep["threads"] == 4
+    # without a request: three quarters of the CPUs the cgroup allows, at most 12; the inflate-only
+    # benchmark sees every byte the records came from
+    env = {k: v for k, v in os.environ.items() if k != "IPX_DECODE_THREADS"}
+    r = subprocess.run([host_check, "bench-decode", bam], stdout=subprocess.PIPE, check=True, env=env)
+    assert 1 <= json.loads(r.stdout)["threads"] <= 12
+    r = subprocess.run([host_check, "bench-inflate", bam, "2"], stdout=subprocess.PIPE, check=True)
+    inf = json.loads(r.stdout)
+    assert inf["threads"] == 2 and inf["inflated_MB"] * 1e6 > 60000 * 180
     raw = bytearray(open(bam, "rb").read())
     bad = str(tmp_path / "bad.bam")
     flipped = bytearray(raw)

@@ -170,6 +170,11 @@ static hipError_t ipx_stream_wait(hipStream_t s) {
     return e;
 }
 
+// the handle's counters, set in stream order (ipx_clear, re-scans)
+__global__ void k_set_counters(Counters *dst, Counters c) {
+    if (threadIdx.x == 0) *dst = c;
+}
+
 // Reading a few words back between stages: a copy command, its completion signal and the host's stream
 // query cost 25-45 us per stage.  Instead the LAST kernel of the stage is k_publish: it writes the words
 // straight into pinned, host-coherent memory and then a sequence number, and the host spins on that number
@@ -306,8 +311,10 @@ int reset_counters(ipx_handle *h) {
     c.err_word = IPX_ERRW_NONE;
     for (int k = 0; k < 3; ++k) { c.key_or[k] = 0; c.key_and[k] = ~0u; h->key_or[k] = 0; h->key_and[k] = ~0u; }
     h->err_word_host = IPX_ERRW_NONE;
-    HIPCHK(hipMemcpyAsync(h->counters.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(ipx_stream_wait(h->stream));
+    // stream-ordered, by a one-wave kernel that takes the values as its argument: a copy from this stack frame
+    // would be staged and waited for (25-80 us per ipx_clear)
+    hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), c);
+    HIPCHK(hipGetLastError());
     return IPX_OK;
 }
 
@@ -601,8 +608,8 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
         // alignment order): repeat with the lane-per-alignment kernel.  Or the capacity estimate was
         // too small: records beyond it were counted but not stored; make room and scan again.
         const uint64_t need = c->n_records;
-        HIPCHK(hipMemcpyAsync(h->counters.p, &before, sizeof before, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(ipx_stream_wait(h->stream));
+        hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), before);
+        HIPCHK(hipGetLastError());
         if (layout_bad) use_ops = false;
         else if (stripes_bad) use_stripes = false;
         else if ((rc = grow_records(h, need))) return rc;

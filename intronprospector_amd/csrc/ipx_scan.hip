@@ -983,8 +983,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 // ---- what k_scan_short left out ------------------------------------------------------------------
 // k_scan_rest: the alignments k_scan_short listed (more than 8 CIGAR ops; every alignment of a tile whose
 // records overflowed the LDS pool), one lane each, op by op: count (run_read<0>), ONE reservation per wave,
-// store (run_read<1>).  Launched only when the first stage listed something (ipx_launch_scan_rest): the
-// op-by-op walk uses scratch memory, and even an empty launch of it costs 18 us.
+// store (run_read<1>).  Launched only when the first stage listed something (ipx_launch_scan_rest): even an
+// empty launch of its 1024 blocks costs 18 us.
 __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, const uint32_t *__restrict__ cigar,
                                                    const uint32_t *__restrict__ defer,
                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,

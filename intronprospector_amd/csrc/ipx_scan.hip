@@ -726,27 +726,33 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         unsigned long long my_err = IPX_ERRW_NONE;
         if (t == 0) { pool_n = 0; cx_n = 0; }
         __syncthreads();
-        // Phase 1, every alignment of the tile: the plain spliced read "aM nN bM" (two thirds of short-read
-        // data) has a closed form -- one junction, anchors a and b, no counters.  Everything else is only
-        // LISTED here and walked in phase 2 by as few waves as it fills: a wave runs the eight-step walk
-        // for all its lanes or for none, so packing the alignments that need it saves most of the walks.
+        // Phase 1, every alignment of the tile: the plain spliced reads "aM nN bM" (two thirds of short-read data)
+        // and "aM nN bM nN cM" (most of the rest) have closed forms -- one or two junctions, anchors a, b, c, no
+        // counters.  Everything else is only LISTED here and walked in phase 2 by as few waves as it fills: a wave
+        // runs the eight-step walk for all its lanes or for none, so packing the alignments that need it saves
+        // most of the walks.
         // (the loads of all RPT rounds first: a round's two dependent round trips overlap the other's)
         ReadCtx c_r[RPT];
-        uint32_t nc_r[RPT], off_r[RPT];
+        uint32_t nc_r[RPT], off_r[RPT], w5_r[RPT];
         uint4 w3_r[RPT];
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r)
             load_ctx(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, c_r[r], nc_r[r], off_r[r], my_err);
 #pragma unroll
-        for (uint32_t r = 0; r < RPT; ++r)
+        for (uint32_t r = 0; r < RPT; ++r) {
             w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
+            w5_r[r] = nc_r[r] == 5 ? cigar[(uint64_t)off_r[r] + 4] : 0u;      // off + nc <= n_words was checked
+        }
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
             const ReadCtx &c = c_r[r];
             const uint32_t nc = nc_r[r];
             const uint4 w3 = w3_r[r];
-            const bool plain = nc == 3 && (w3.x & 0xfu) == 0 && (w3.y & 0xfu) == 3 && (w3.z & 0xfu) == 0;
-            const bool walk_it = nc != 0 && !plain;
+            const uint32_t w5 = w5_r[r];
+            const bool mnm = (w3.x & 0xfu) == 0 && (w3.y & 0xfu) == 3 && (w3.z & 0xfu) == 0;
+            const bool plain = nc == 3 && mnm;
+            const bool two = nc == 5 && mnm && (w3.w & 0xfu) == 3 && (w5 & 0xfu) == 0;
+            const bool walk_it = nc != 0 && !plain && !two;
             const unsigned long long wm = ipx_ballot(walk_it);
             if (wm) {
                 const int first = __ffsll(wm) - 1;
@@ -756,19 +762,37 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 if (walk_it) cx_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))] =
                     (uint16_t)(r * BT + t);
             }
-            // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, finish(): one record (junctions_extractor.cc:208-254,278-282)
-            const uint32_t a = w3.x >> 4, nl = w3.y >> 4, b = w3.z >> 4;
-            const bool pass = plain && !c.read_rejected && nl >= p.min_intron_length && nl <= p.max_intron_length &&
-                              a >= p.min_anchor_length && b >= p.min_anchor_length;      // junction_qc :392-397
-            const unsigned long long em = ipx_ballot(pass);
-            if (em) {
-                const uint32_t slot = pool_slot(em);
-                if (pass && slot < POOL) {
+            // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, then either finish(): one record, or N: the record,
+            // its right anchor becomes the next left anchor, -> INTRON, M: -> RIGHT, finish(): the second record
+            // (junctions_extractor.cc:208-254,278-282).  Five lengths below 2^28 cannot leave 32 bits.
+            const uint32_t a = w3.x >> 4, n1 = w3.y >> 4, b = w3.z >> 4, n2 = w3.w >> 4, c5 = w5 >> 4;
+            const bool pass1 = (plain || two) && !c.read_rejected && n1 >= p.min_intron_length && n1 <= p.max_intron_length &&
+                               a >= p.min_anchor_length && b >= p.min_anchor_length;     // junction_qc :392-397
+            const bool pass2 = two && !c.read_rejected && n2 >= p.min_intron_length && n2 <= p.max_intron_length &&
+                               b >= p.min_anchor_length && c5 >= p.min_anchor_length;
+            const unsigned long long em1 = ipx_ballot(pass1);
+            if (em1) {
+                const uint32_t slot = pool_slot(em1);
+                if (pass1 && slot < POOL) {
                     ReadCtx cc = c;
                     cc.pos = 0;
                     uint4 it, pay;
-                    const Rec rr{0, (int64_t)a, (int64_t)(a + nl), (int64_t)(a + nl + b), 0, 0, 0, 0};
+                    const Rec rr{0, (int64_t)a, (int64_t)(a + n1), (int64_t)(a + n1 + b), 0, 0, 0, 0};
                     pack_record_rel(p, cc, rr, (uint32_t)c.pos, 0u, it, pay);
+                    pool_item[slot] = it;
+                    pool_pay[slot] = pay;
+                }
+            }
+            const unsigned long long em2 = ipx_ballot(pass2);
+            if (em2) {
+                const uint32_t slot = pool_slot(em2);
+                if (pass2 && slot < POOL) {
+                    ReadCtx cc = c;
+                    cc.pos = 0;
+                    uint4 it, pay;
+                    const uint32_t s2 = a + n1 + b;
+                    const Rec rr{(int64_t)(a + n1), (int64_t)s2, (int64_t)(s2 + n2), (int64_t)(s2 + n2 + c5), 0, 0, 0, 0};
+                    pack_record_rel(p, cc, rr, (uint32_t)c.pos, pass1 ? 1u : 0u, it, pay);      // ordinals count QC-passed records
                     pool_item[slot] = it;
                     pool_pay[slot] = pay;
                 }

@@ -111,7 +111,7 @@ bool AlnReader::read_sam(AlnRecord &rec) {
     }
     if (nf < 11) throw std::runtime_error("Error reader BAM record: " + path_);
     if (keep_raw_) rec.raw = line_;
-    rec.qname.assign(f[0], flen[0]);
+    if (keep_qname_) rec.qname.assign(f[0], flen[0]);
     rec.flag = (uint16_t)strtol(f[1], nullptr, 0);
     rec.tid = -1;
     if (!(flen[2] == 1 && f[2][0] == '*')) {
@@ -217,7 +217,7 @@ bool AlnReader::read_bam(AlnRecord &rec) {
     const uint32_t l_seq = le32(b + 16);
     size_t off = 32;
     if (off + l_read_name > block) throw std::runtime_error("Error reader BAM record: " + path_);
-    rec.qname.assign((const char *)b + off, l_read_name ? l_read_name - 1 : 0);
+    if (keep_qname_) rec.qname.assign((const char *)b + off, l_read_name ? l_read_name - 1 : 0);
     off += l_read_name;
     if (off + 4ull * n_cigar > block) throw std::runtime_error("Error reader BAM record: " + path_);
     rec.cigar.resize(n_cigar);

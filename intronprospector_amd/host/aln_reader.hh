@@ -44,6 +44,8 @@ public:
     bool is_bam() const { return bam_; }
     // pass-through needs the records and the header as they came
     void keep_raw(bool on) { keep_raw_ = on; }
+    // read names are only wanted by --debug-trace; leaving them out saves a string assignment per record
+    void keep_qname(bool on) { keep_qname_ = on; }
     // SAM: the header lines; BAM: everything between the magic and the first record (l_text ... refs)
     const std::string &raw_header() const { return raw_header_; }
     unsigned decode_threads() const { return bgzf_ ? bgzf_->threads() : 1; }
@@ -56,6 +58,7 @@ private:
     std::unique_ptr<BgzfReader> bgzf_;       // BAM: blocks inflated by a thread pool
     bool bam_ = false;
     bool keep_raw_ = false;
+    bool keep_qname_ = true;
     std::string raw_header_;
     std::vector<std::string> names_;
     std::vector<int64_t> lengths_;

@@ -77,6 +77,7 @@ void JunctionsExtractor::throw_last_error(int status) {
 void JunctionsExtractor::open(const std::string &bam) {
     bam_ = bam;
     reader_.reset(new AlnReader(bam));
+    reader_->keep_qname(trace_fh_ != nullptr);        // read names only go into the --debug-trace rows
     for (const std::string &nm : reader_->target_names()) {
         int32_t first = (int32_t)targets_.size();
         for (size_t i = 0; i < targets_.size(); ++i)

@@ -45,7 +45,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
     constexpr uint32_t BPT = TILE / SORT_THREADS, WPT = BPT / 4;      // digit bytes (words) per thread and tile
     __shared__ uint32_t hs[GROUP][256];
     const uint32_t n_groups = (n_tiles + GROUP - 1) / GROUP;
-    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    for (uint32_t it = blockIdx.x; it < n_groups; it += gridDim.x) {
+        // a grid of exactly n_groups blocks gives every XCD (blockIdx mod 8) one contiguous range of groups, as
+        // k_scatter does: the 4-byte counts of neighbouring tiles share the lines of a bin's row
+        uint32_t group = it;
+        if (gridDim.x == n_groups && n_groups >= 256) {
+            const uint32_t x = it & 7u, k = it >> 3, q = n_groups >> 3, r = n_groups & 7u;
+            group = x * q + (x < r ? x : r) + k;
+        }
 #pragma unroll
         for (uint32_t g = 0; g < GROUP; ++g) hs[g][threadIdx.x] = 0;
         __syncthreads();
@@ -426,7 +433,7 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     const uint32_t group = ge ? (uint32_t)atoi(ge) : (big ? 1u : 8u);
     const bool grouped = (uint64_t)n_tiles * tile_items >= (4u << 20);
     const uint32_t n_groups = grouped ? (n_tiles + group - 1) / group : n_tiles;
-    const uint32_t hist_grid = n_groups < 2048 ? n_groups : 2048;
+    const uint32_t hist_grid = n_groups <= 8192 ? n_groups : 2048;      // one block per group while that is cheap
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
     static const uint32_t xcd_env = [] { const char *e = getenv("IPX_SCATTER_XCD"); return e ? (uint32_t)atoi(e) : 1u; }();

@@ -89,12 +89,17 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
                                                      unsigned long long *__restrict__ creator,
                                                      unsigned long long *__restrict__ counts,
                                                      uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
-                                                     uint32_t *__restrict__ bin_count, uint32_t *__restrict__ totals) {
+                                                     uint32_t *__restrict__ bin_count, uint32_t *__restrict__ totals,
+                                                     uint32_t *__restrict__ jmotif0, uint32_t n_j, uint32_t n_b) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t base = chunk * CHUNK;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[2] = 0; totals[3] = 0; totals[4] = 0; totals[5] = ~0u; totals[6] = ~0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        totals[2] = 0; totals[3] = 0; totals[4] = 0; totals[5] = ~0u; totals[6] = ~0u;
+        // without a genome nothing is dropped later (jmotif0 != null): the table has all n_j junctions and n_b bins
+        if (jmotif0) { totals[0] = n_j; totals[1] = n_b; }
+    }
     if (base >= n) return;
     uint32_t nj = chunk_j[chunk], nb = chunk_b[chunk];     // heads before this chunk
 #pragma unroll
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
             bin_count[bid] = 0;                  // the rows k_reduce accumulates into start at the identity
             if (h.head_j) {
                 jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; jfirstbin[jid] = bid;
+                if (jmotif0) jmotif0[jid] = 0;           // what k_motif would write without a genome
                 first[jid] = ~0ull; creator[jid] = ~0ull;
                 amin[jid] = ~0u; amax[jid] = 0u;
                 counts[3ull * jid] = 0; counts[3ull * jid + 1] = 0; counts[3ull * jid + 2] = 0;
@@ -502,12 +508,12 @@ __global__ __launch_bounds__(256) void k_emit_bins(uint32_t n_b, const uint32_t 
                                                    const uint32_t *__restrict__ bin_off,
                                                    const uint32_t *__restrict__ bin_pos,
                                                    uint16_t *__restrict__ hist_value,
-                                                   uint32_t *__restrict__ hist_count) {
+                                                   uint32_t *__restrict__ hist_count, uint32_t identity) {
     const uint32_t bidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (bidx >= n_b) return;
     const uint32_t c = bin_count[bidx];
     if (c) {
-        const uint32_t p = bin_pos[bidx];
+        const uint32_t p = identity ? bidx : bin_pos[bidx];
         hist_value[p] = (uint16_t)bin_off[bidx];
         hist_count[p] = c;
     }
@@ -530,7 +536,8 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jfirstbin,
     const uint32_t *__restrict__ bin_pos,
     const uint32_t *__restrict__ tid_of_rank, const uint32_t *n_valid_total,
-    const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items, uint32_t *__restrict__ rank_bits) {
+    const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items, uint32_t *__restrict__ rank_bits,
+    uint32_t identity) {
     __shared__ uint32_t bits_s[4][4];
     if (blockIdx.x == 0 && threadIdx.x == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
     // creation order packed as read_index << (bits of the largest ordinal) | ordinal; the OR / AND of those
@@ -538,8 +545,8 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     const uint32_t ord_bits = 32u - (uint32_t)__clz((int)rank_bits[0]);
     uint32_t o0 = 0, o1 = 0, a0 = ~0u, a1 = ~0u;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_j; j += gridDim.x * blockDim.x) {
-        if (!jvalid[j]) continue;
-        const uint32_t o = jpos[j];
+        if (!identity && !jvalid[j]) continue;
+        const uint32_t o = identity ? j : jpos[j];
         out.target[o] = tid_of_rank[jrank[j]];
         out.intron_start[o] = jstart[j];
         out.intron_end[o] = jend[j];
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
         out.read_counts[(uint64_t)o * 3 + 2] = counts[(uint64_t)j * 3 + 2];
         const unsigned long long cr = creator[j];
         out.creator_order[o] = IPX_ORD_SEQ(cr);
-        out.hist_begin[o] = bin_pos[jfirstbin[j]];      // bins are ordered by (junction, offset)
+        out.hist_begin[o] = identity ? jfirstbin[j] : bin_pos[jfirstbin[j]];      // bins are ordered by (junction, offset)
         const unsigned long long rk = (IPX_ORD_READ(cr) << ord_bits) | ((cr >> IPX_ORD_SHIFT_ORDINAL) & IPX_ORD_MAX_ORDINAL);
         rank_items[o] = make_uint4((uint32_t)rk, (uint32_t)(rk >> 32), 0u, o);
         o0 |= (uint32_t)rk; o1 |= (uint32_t)(rk >> 32);
@@ -658,12 +665,19 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters) {
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
     const uint32_t J = rb.n_j, B = rb.n_b;
+    // Without a genome there are no motifs, no filter and no fetch errors: every junction has a creator (its
+    // first record) and every bin a counted record, so nothing is dropped and the table keeps the order and
+    // the count of the segments -- no motif kernel, no flags, no compaction scans.
+    const uint32_t identity = genome.seq_of_rank == nullptr ? 1u : 0u;
     hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
-                       rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, rb.totals);
+                       rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, rb.totals,
+                       identity ? rb.jmotif : nullptr, J, B);
     ipx_prof_mark(s, IPXK_WRITE_HEADS);
-    hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
-                       rb.jstart, rb.jend, rb.jmotif);
-    ipx_prof_mark(s, IPXK_MOTIF);
+    if (!identity) {
+        hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
+                           rb.jstart, rb.jend, rb.jmotif);
+        ipx_prof_mark(s, IPXK_MOTIF);
+    }
     hipError_t e;
     // A record can fail the filter only against a motif and under "canon" (splice_juncs.cc:52-61)
     const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
@@ -683,20 +697,22 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     hipLaunchKernelGGL(k_finish_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.first, rb.creator,
                        rb.jmotif, rb.jvalid, rb.jstrand, counters, rb.totals + 2);
     ipx_prof_mark(s, IPXK_FINISH_J);
-    hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_flag);
-    ipx_prof_mark(s, IPXK_BINS);
-    // compaction offsets: junctions, bins, bins per junction
-    if ((e = ipx_launch_scan_u32_pair(s, rb.jvalid, rb.jpos, J, rb.totals + 0, rb.bin_flag, rb.bin_pos, B, rb.totals + 1,
-                                      rb.scan_sums)) != hipSuccess) return e;
+    if (!identity) {
+        hipLaunchKernelGGL(k_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_flag);
+        ipx_prof_mark(s, IPXK_BINS);
+        // compaction offsets: junctions, bins, bins per junction
+        if ((e = ipx_launch_scan_u32_pair(s, rb.jvalid, rb.jpos, J, rb.totals + 0, rb.bin_flag, rb.bin_pos, B, rb.totals + 1,
+                                          rb.scan_sums)) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
-                       rb.bin_pos, rb.out_hist_value, rb.out_hist_count);
+                       rb.bin_pos, rb.out_hist_value, rb.out_hist_count, identity);
     ipx_prof_mark(s, IPXK_EMIT_BINS);
     TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
                 rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
                 rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
     hipLaunchKernelGGL(k_emit_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
-                       rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a, rb.totals + 2);
+                       rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a, rb.totals + 2, identity);
     ipx_prof_mark(s, IPXK_EMIT_J);
     return hipGetLastError();
 }

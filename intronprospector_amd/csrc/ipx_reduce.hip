@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
                                                      unsigned long long *__restrict__ counts,
                                                      uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
                                                      uint32_t *__restrict__ bin_count, uint32_t *__restrict__ totals,
-                                                     uint32_t *__restrict__ jmotif0, uint32_t n_j, uint32_t n_b) {
+                                                     uint32_t *__restrict__ jmotif0, uint32_t n_j, uint32_t n_b,
+                                                     uint16_t *__restrict__ hist_value0) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
         const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
         if (h.head_b) {
             const KeyParts k = unpack_key(h.it, kl);
-            bin_off[bid] = k.off16;
+            if (hist_value0) hist_value0[bid] = (uint16_t)k.off16;      // straight into the table (no genome: bins keep their places)
+            else bin_off[bid] = k.off16;
             bin_count[bid] = 0;                  // the rows k_reduce accumulates into start at the identity
             if (h.head_j) {
                 jrank[jid] = k.rank; jstart[jid] = k.start; jend[jid] = k.end; jfirstbin[jid] = bid;
@@ -669,9 +671,11 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     // first record) and every bin a counted record, so nothing is dropped and the table keeps the order and
     // the count of the segments -- no motif kernel, no flags, no compaction scans.
     const uint32_t identity = genome.seq_of_rank == nullptr ? 1u : 0u;
+    // ... and the bins' offsets and counts are written where the table has them (no k_emit_bins)
+    uint32_t *bin_count = identity ? rb.out_hist_count : rb.bin_count;
     hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
-                       rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, rb.totals,
-                       identity ? rb.jmotif : nullptr, J, B);
+                       rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, rb.totals,
+                       identity ? rb.jmotif : nullptr, J, B, identity ? rb.out_hist_value : nullptr);
     ipx_prof_mark(s, IPXK_WRITE_HEADS);
     if (!identity) {
         hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
@@ -684,7 +688,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     if (!filter_active) {
         ipx_prof_pre(s, IPXK_PHASE_B);
         hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
-                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters);
         ipx_prof_mark(s, IPXK_PHASE_B);
     } else {
         hipLaunchKernelGGL(k_reduce<1>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
@@ -704,9 +708,11 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
         if ((e = ipx_launch_scan_u32_pair(s, rb.jvalid, rb.jpos, J, rb.totals + 0, rb.bin_flag, rb.bin_pos, B, rb.totals + 1,
                                           rb.scan_sums)) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
-                       rb.bin_pos, rb.out_hist_value, rb.out_hist_count, identity);
-    ipx_prof_mark(s, IPXK_EMIT_BINS);
+    if (!identity) {
+        hipLaunchKernelGGL(k_emit_bins, grid1d(B, 256), dim3(256), 0, s, B, rb.bin_count, rb.bin_off,
+                           rb.bin_pos, rb.out_hist_value, rb.out_hist_count, identity);
+        ipx_prof_mark(s, IPXK_EMIT_BINS);
+    }
     TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
                 rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
                 rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};

@@ -243,10 +243,11 @@ __device__ __forceinline__ void flush_junction(bool plain, uint32_t jid, const J
     if (MODE == 0 || MODE == 1) {
         if (plain) {
             first[jid] = a.m1;
-            creator[jid] = a.m2;
+            creator[jid] = (MODE == 0) ? a.m1 : a.m2;
         } else {
             atomicMin(&first[jid], a.m1);
-            if (a.m2 != NONE64) atomicMin(&creator[jid], a.m2);
+            if (MODE == 0) atomicMin(&creator[jid], a.m1);
+            else if (a.m2 != NONE64) atomicMin(&creator[jid], a.m2);
         }
     }
     if (MODE == 0 || MODE == 2) {
@@ -266,26 +267,29 @@ __device__ __forceinline__ void flush_junction(bool plain, uint32_t jid, const J
     }
 }
 
+// MODE 0 never looks at m2 (its creator is m1): the four registers it would take carried around are worth a wave
+template <int MODE>
 __device__ __forceinline__ JAcc merge_acc(const JAcc &x, const JAcc &y) {
     JAcc r;
     r.m1 = x.m1 < y.m1 ? x.m1 : y.m1;
-    r.m2 = x.m2 < y.m2 ? x.m2 : y.m2;
+    r.m2 = (MODE == 0) ? NONE64 : (x.m2 < y.m2 ? x.m2 : y.m2);
     r.c0 = x.c0 + y.c0; r.c1 = x.c1 + y.c1; r.c2 = x.c2 + y.c2;
     r.lo = x.lo < y.lo ? x.lo : y.lo;
     r.hi = x.hi > y.hi ? x.hi : y.hi;
     return r;
 }
 
+template <int MODE>
 __device__ __forceinline__ JAcc bcast_acc(const JAcc &x, int src) {
     JAcc r;
-    r.m1 = __shfl(x.m1, src); r.m2 = __shfl(x.m2, src);
+    r.m1 = __shfl(x.m1, src); r.m2 = (MODE == 0) ? NONE64 : __shfl(x.m2, src);
     r.c0 = __shfl(x.c0, src); r.c1 = __shfl(x.c1, src); r.c2 = __shfl(x.c2, src);
     r.lo = __shfl(x.lo, src); r.hi = __shfl(x.hi, src);
     return r;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
+__global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
                                                 const uint4 *__restrict__ pays,
                                                 const uint32_t *__restrict__ chunk_j,
                                                 const uint32_t *__restrict__ chunk_b,
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
                 cnt_it = (cr != NONE64) && IPX_ORD_SEQ(ord) >= IPX_ORD_SEQ(cr);
             } else {
                 v.m1 = ord;
-                v.m2 = ord;
+                v.m2 = NONE64;            // MODE 0: the creator is m1
             }
             if (cnt_it) {
                 counted = 1;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
         const uint32_t last_j = seg_last_lane(heads_j, lane);
         if (MODE != 2) {
             v.m1 = seg_reduce(v.m1, lane, last_j, MinU64());
-            v.m2 = (MODE == 0) ? v.m1 : seg_reduce(v.m2, lane, last_j, MinU64());   // MODE 0: first == creator
+            if (MODE != 0) v.m2 = seg_reduce(v.m2, lane, last_j, MinU64());          // MODE 0: first == creator, m2 is dead
         }
         if (MODE != 1) {
             uint32_t cpk = v.c0 | (v.c1 << 8) | (v.c2 << 16);          // <= 64 per field and round
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
             bool here0 = false;                              // did lane 0's segment begin inside this chunk?
             if (cj_valid) {
                 if (cont0 && cj_id == jid0) {
-                    if (lane == 0) v = merge_acc(v, cj);
+                    if (lane == 0) v = merge_acc<MODE>(v, cj);
                     here0 = cj_here;
                 } else if (lane == 0) {
                     flush_junction<MODE>(cj_here, cj_id, cj, first, creator, counts, amin, amax);
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void k_reduce(const uint4 *__restrict__ items,
             const uint64_t carry_mask = ipx_ballot(is_head && runs_on);
             if (carry_mask) {
                 const int src = __ffsll((unsigned long long)carry_mask) - 1;
-                cj = bcast_acc(v, src);
+                cj = bcast_acc<MODE>(v, src);
                 cj_id = __shfl(jid, src);
                 cj_here = __shfl((int)began_here, src) != 0;
                 cj_valid = true;

@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10M for S, 200k for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shuffle", action="store_true",
+                    help="alignments in random order instead of coordinate order (the reference's whole-file mode "
+                         "accepts unsorted input): what the step costs without any locality")
     ap.add_argument("--multi", default="exchange", choices=["exchange", "tables"],
                     help="N>1: exchange junction records by key range (default) or merge shard tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -124,6 +127,9 @@ def main():
     seed = (synth.SEED_L if kind == "L" else synth.SEED_S) if world == 1 else synth.SEED_M0 + rank
     t_gen = time.perf_counter()
     batch, names, genome = make_workload(kind, reads, seed)
+    if args.shuffle:
+        import numpy as np
+        batch = synth.permute_batch(batch, np.random.default_rng(seed + 7).permutation(len(batch["tid"])))
     t_gen = time.perf_counter() - t_gen
     n = len(batch["tid"])
     n_words = len(batch["cigar"])
@@ -261,7 +267,7 @@ def main():
                                     (", device 2-bit genome, --sj-filter=canon" if kind == "G" else ""),
                                     c, j, n_junctions),
                        "alignments_per_gpu": n, "cigar_words": n_words, "records": r, "junctions": n_junctions,
-                       "seed": seed, "generate_s": t_gen},
+                       "order": "shuffled" if args.shuffle else "coordinate-sorted", "seed": seed, "generate_s": t_gen},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -351,6 +351,20 @@ def concat_batches(batches):
     return out
 
 
+def permute_batch(batch, perm):
+    """The alignments of a batch in the order perm (CIGAR words moved along, offsets rebuilt)."""
+    perm = np.asarray(perm, np.int64)
+    nc = batch["n_cigar"][perm].astype(np.int64)
+    off_old = batch["cigar_off"][perm].astype(np.int64)
+    off_new = np.zeros(len(perm), np.int64)
+    np.cumsum(nc[:-1], out=off_new[1:])
+    src = np.repeat(off_old - off_new, nc) + np.arange(int(nc.sum()), dtype=np.int64)
+    out = {k: batch[k][perm].copy() for k in ("tid", "pos", "flag", "xs", "nh", "n_cigar")}
+    out["cigar_off"] = off_new.astype(np.uint32)
+    out["cigar"] = batch["cigar"][src].copy()
+    return out
+
+
 def slice_batch(batch, lo, hi):
     """Alignments [lo, hi) of a batch as a self-contained batch."""
     if hi <= lo:

@@ -72,6 +72,19 @@ def test_short_reads_multiple_pushes_equal_single():
     helpers.compare_tables(dev, ora)
 
 
+def test_short_reads_in_random_order_match_oracle():
+    """identify_junctions_for_bam (junctions_extractor.cc:678-683) takes unsorted input: creation order, and with
+    it sjN, follows the input order, nothing else changes."""
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(60_000, seed=33, n_targets=3, target_len=4_000_000, n_sites=1500)
+    shuffled = synth.permute_batch(batch, np.random.default_rng(34).permutation(len(batch["tid"])))
+    dev, ora, err = _run_both(shuffled, names, {}, n_push=2)
+    assert err is None
+    helpers.compare_tables(dev, ora)
+    sorted_dev, sorted_ora, _ = _run_both(batch, names, {})
+    assert np.array_equal(sorted_ora["counts"], ora["counts"]) and not np.array_equal(sorted_ora["ijunc"], ora["ijunc"])
+
+
 def test_finalize_then_push_more_then_finalize_again():
     """The table may be asked for repeatedly while records accumulate (multi-input mode of the
     host): a second sort starts from an already permuted record array."""

@@ -1081,9 +1081,11 @@ __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, co
 // record count and zeroes the stripe counters for the next launch.  A launch that ran out of capacity
 // publishes the extent it would have needed instead (the caller grows the arrays and repeats the scan).
 struct StripeState {
-    unsigned long long count[IPX_STRIPES];
     unsigned long long n, extent, window_lo;
 };
+__device__ __forceinline__ unsigned long long stripe_count(const Counters *counters, uint32_t k) {
+    return *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(counters) + IPX_CNT_STRIPE0 + 128 * k);
+}
 
 __device__ __forceinline__ StripeState stripe_state(const Counters *counters) {
     StripeState st;
@@ -1091,9 +1093,7 @@ __device__ __forceinline__ StripeState stripe_state(const Counters *counters) {
     st.extent = 0;
     unsigned long long rounds = ~0ull;
     for (uint32_t k = 0; k < IPX_STRIPES; ++k) {
-        const unsigned long long c = *reinterpret_cast<const unsigned long long *>(
-            reinterpret_cast<const char *>(counters) + IPX_CNT_STRIPE0 + 128 * k);
-        st.count[k] = c;
+        const unsigned long long c = stripe_count(counters, k);
         st.n += c;
         if (c) {
             const unsigned long long last = c - 1;
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_close_find(Counters *counters, uint64_t
         const uint64_t chunk = pos >> IPX_STRIPE_CHUNK_BITS;
         const uint32_t k = (uint32_t)(chunk & (IPX_STRIPES - 1));
         const uint64_t i = ((chunk / IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS) | (pos & ((1u << IPX_STRIPE_CHUNK_BITS) - 1));
-        const bool taken = pos < st.extent && i < st.count[k];
+        const bool taken = pos < st.extent && i < stripe_count(counters, k);      // (a per-lane index into a register array would live in scratch)
         const bool hole = pos < st.n && !taken, tail = pos >= st.n && taken;
         const unsigned long long hm = ipx_ballot(hole), tm = ipx_ballot(tail);
         if (hm) {

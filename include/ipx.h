@@ -204,8 +204,10 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *batch);
 /* Sort + reduce every record pushed since the last ipx_clear into the junction
  * table.  memory selects where the returned arrays live.  If the input raised a
  * reference exception the call returns IPX_EDATA and ipx_last_error() tells
- * which alignment and why (the earliest one in input order); *out then
- * describes the table of the records BEFORE that alignment. */
+ * which alignment and why (the earliest one in input order).  The reference
+ * throws at that alignment and its caller never sees a table; *out is then
+ * filled from the records of all other alignments and has no reference
+ * counterpart. */
 int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out);
 
 /* JunctionsExtractor::clear(), junctions_extractor.hh:223-225: drops records and

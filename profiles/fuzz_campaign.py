@@ -11,6 +11,22 @@ from intronprospector_amd import synth
 from oracle_binding import Oracle, OracleError
 
 
+def make_genome(rng):
+    """short reads over a synthetic genome: -> batch, names, extractor genome argument, FASTA path, junction filter"""
+    import tempfile
+    b, names, gen = synth.short_reads(int(rng.integers(2000, 40000)), seed=int(rng.integers(1, 1 << 30)), n_targets=3,
+                                      target_len=2_700_000, n_sites=int(rng.integers(20, 900)), genome=True)
+    fasta = os.path.join(tempfile.mkdtemp(), "g.fa")
+    gen.write_fasta(fasta)
+    gen2 = (gen.names, [(t, m, len(q)) for (t, m), q in zip(gen.twobit(), gen.seqs)])
+    if rng.integers(0, 3) == 0:
+        b = synth.permute_batch(b, rng.permutation(len(b["tid"])))
+    def fetch(tid, start, end, seqs=gen.seqs):
+        q = seqs[tid]
+        return bytes([q[start], q[start + 1], q[end - 2], q[end - 1]])
+    return b, names, gen2, fasta, int(rng.integers(0, 3)), fetch
+
+
 def make(rng):
     kind = rng.integers(0, 6)
     names = ["chrB", "chrA", "chrC"]
@@ -55,19 +71,26 @@ def main():
     n_err = 0
     for it in range(n_iter):
         rng = np.random.default_rng(seed0 + it)
-        batch, names = make(rng)
+        gen2, fasta, fetch = None, None, None
+        with_genome = rng.integers(0, 4) == 0
+        if with_genome:
+            batch, names, gen2, fasta, jf, fetch = make_genome(rng)
+        else:
+            batch, names = make(rng)
         params = {"min_anchor_length": int(rng.choice([1, 3, 8, 20])), "max_anchor_indel_size": int(rng.choice([0, 4, 36])),
                   "min_intron_length": int(rng.choice([1, 70, 200])), "max_intron_length": int(rng.choice([2000, 500000, 4000000])),
                   "strandness": int(rng.integers(0, 3)), "excludes": int(rng.integers(0, 2))}
+        if with_genome:
+            params["junction_filter"] = jf
         n_push = int(rng.integers(1, 4))
-        ex = ipa.JunctionsExtractor(targets=names, **params)
+        ex = ipa.JunctionsExtractor(targets=names, genome=gen2, **params)
         n = len(batch["tid"])
         cuts = np.linspace(0, n, n_push + 1).astype(int)
         for a, b in zip(cuts[:-1], cuts[1:]):
             ex.push(synth.slice_batch(batch, int(a), int(b)))
         dev = ex.get_junctions()
         ex.close()
-        ora = Oracle(targets=names, **params)
+        ora = Oracle(targets=names, genome_fasta=fasta, **params)
         err = None
         try:
             ora.process(batch)
@@ -82,7 +105,7 @@ def main():
                 n_err += 1
             else:
                 assert "error" not in dev
-                helpers.compare_tables(dev, tab)
+                helpers.compare_tables(dev, tab, fetch)
         except AssertionError as x:
             bad += 1
             print(json.dumps({"seed": seed0 + it, "alignments": n, "params": params, "n_push": n_push, "failure": str(x)[:300]}))

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IPX_ABI_VERSION 1
+#define IPX_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -193,6 +193,15 @@ int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names
                         const int64_t *lengths, const uint8_t *const *twobit,
                         const uint8_t *const *mask);
 
+/* Handle options.
+ *   IPX_OPT_COMBINE (default 1)  the short-read scan may merge, tile by tile, junction records that share
+ *       junction AND read offset into one record that stands for all of them (ipx_table is unaffected: the
+ *       merged record carries the group's counts, extreme anchors and earliest order).  Set it to 0 before
+ *       the first push when the caller wants every single record back (ipx_records_export: --debug-trace,
+ *       strand tags in the pass-through, junctions_extractor.cc:451-457,471-477,526-528). */
+enum { IPX_OPT_COMBINE = 1 };
+int ipx_set_option(ipx_handle *h, int32_t option, int64_t value);
+
 /* Optional: size device buffers once, before timing. */
 int ipx_reserve(ipx_handle *h, uint64_t n_alignments, uint64_t n_cigar_words, uint64_t n_records);
 
@@ -242,7 +251,9 @@ int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creato
  *   ipx_records_partition  n_parts (<= 64) parts: part p holds the keys in
  *                          [splitters[p-1], splitters[p]); counts[p] records each; the
  *                          32-byte records are written part after part to dst_records
- *                          (device memory, room for ipx_records_pending records)
+ *                          (device memory, room for ipx_records_pending records).  A
+ *                          record may stand for several reads (IPX_OPT_COMBINE); its
+ *                          counts travel inside the 32 bytes
  *   ipx_records_adopt      replaces the handle's pending records by n received ones */
 int ipx_records_pending(const ipx_handle *h, uint64_t *n_records);
 int ipx_records_sample(ipx_handle *h, uint32_t n_samples, uint64_t *out_keys);

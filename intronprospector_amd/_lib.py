@@ -24,8 +24,9 @@ SYMBOLS = [
     "ipx_reserve", "ipx_push_batch", "ipx_finalize", "ipx_clear", "ipx_last_error",
     "ipx_finalize_shard", "ipx_copy", "ipx_records_pending", "ipx_records_sample",
     "ipx_records_partition", "ipx_records_adopt", "ipx_records_export", "ipx_last_timing", "ipx_profile",
-    "ipx_profile_only", "ipx_profile_read",
+    "ipx_profile_only", "ipx_profile_read", "ipx_set_option",
 ]
+IPX_OPT_COMBINE = 1
 
 
 class Params(C.Structure):
@@ -91,6 +92,7 @@ def load():
     lib.ipx_set_genome_2bit.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                         C.POINTER(vp), C.POINTER(vp)]
     lib.ipx_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.ipx_set_option.argtypes = [vp, C.c_int32, C.c_int64]
     lib.ipx_push_batch.argtypes = [vp, C.POINTER(Batch)]
     lib.ipx_finalize.argtypes = [vp, C.c_int32, C.POINTER(Table)]
     lib.ipx_clear.argtypes = [vp]

@@ -114,7 +114,9 @@ struct ipx_handle {
     std::vector<int64_t> glen;
     DevBuf d_twobit, d_mask, d_seq_len, d_seq_word2, d_seq_wordm, d_seq_of_rank;
     // records
-    DevBuf items_a, items_b, pays, dig_a, dig_b;
+    DevBuf items_a, items_b, pays, cnts, dig_a, dig_b;
+    bool opt_combine = true;       // IPX_OPT_COMBINE: the short-read scan may merge equal-key records of a tile
+    uint64_t n_raw = 0;            // junction records that passed junction_qc (>= n_records once records were combined)
     uint32_t key_or[3] = {0, 0, 0}, key_and[3] = {~0u, ~0u, ~0u};   // host copy of Counters::key_or/and
     uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
     uint64_t seen_words = 0, seen_records = 0;     // for the capacity estimate
@@ -325,8 +327,10 @@ int grow_records(ipx_handle *h, uint64_t cap) {
     int rc;
     if ((rc = ensure(h, h->items_a, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
     if ((rc = ensure(h, h->pays, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, h->cnts, cap * sizeof(uint32_t), true, h->n_records * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->dig_a, cap + 64, true, h->n_records))) return rc;
-    h->rec_cap = std::min(std::min(h->items_a.cap, h->pays.cap) / sizeof(uint4), h->dig_a.cap - 64);
+    h->rec_cap = std::min(std::min(std::min(h->items_a.cap, h->pays.cap) / sizeof(uint4), h->cnts.cap / sizeof(uint32_t)),
+                          h->dig_a.cap - 64);
     return IPX_OK;
 }
 
@@ -416,7 +420,7 @@ int ipx_destroy(ipx_handle *h) {
     (void)hipSetDevice(h->params.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
-                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->dig_a, &h->dig_b,
+                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
                       &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer})
         release(*b);
@@ -555,6 +559,13 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     sp.key = h->key;
     if (h->n_records == 0) h->first_window = h->first_hint;
     sp.first = h->first_window;
+    // Combining a tile's equal-key records is exact when every record of a junction is counted, i.e. when none
+    // can fail the junction filter: no genome, or a filter other than "canon" (splice_juncs.cc:52-61).  With an
+    // active filter the records before a junction's creator are dropped one by one (ipx_reduce.hip), which a
+    // merged record could straddle.  IPX_COMBINE=0 in the environment switches it off (tests compare both).
+    static const bool combine_env = [] { const char *e = getenv("IPX_COMBINE"); return !(e && e[0] == '0'); }();
+    const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
+    sp.combine = (h->opt_combine && combine_env && !filter_active) ? 1u : 0u;
 
     ProfScope prof_scope(&h->prof);
     // state to return to if a scan has to be repeated
@@ -571,24 +582,28 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         if (use_ops)
             HIPCHK(ipx_launch_scan_ops(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                       h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>()));
+                                       h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap,
+                                       h->counters.as<Counters>()));
         else
             HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                   h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
+                                   h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
                                    h->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
                                    h->defer.as<uint32_t>()));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         const uint32_t *defer_n_dev = reinterpret_cast<const uint32_t *>(h->counters.as<char>() + IPX_CNT_DEFER);
-        if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, defer_n_dev, 1))) return rc;
+        // [defer count, -, merged records (64 bit)]: IPX_CNT_DEFER and IPX_CNT_MERGED are neighbours
+        if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, defer_n_dev, 4))) return rc;
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
+        const uint32_t *tail4 = (const uint32_t *)h->pin_small + sizeof(Counters) / 4;
+        const uint64_t merged = use_ops ? 0ull : ((uint64_t)tail4[2] | ((uint64_t)tail4[3] << 32));
         const bool layout_bad = use_ops && c->pad[0] != 0;
         bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
         // second stage: alignments the short-CIGAR kernel only listed (more than 8 ops, overflowing tiles)
         const uint32_t n_defer = use_ops ? 0u : ((const uint32_t *)h->pin_small)[sizeof(Counters) / 4];
         if (n_defer && !layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             HIPCHK(ipx_launch_scan_rest(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                        h->pays.as<uint4>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
+                                        h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
                                         c->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
                                         h->defer.as<uint32_t>(), n_defer));
             HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -601,6 +616,7 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
             h->err_word_host = c->err_word;
             h->seen_words += nw;
             h->seen_records += c->n_records - h->n_records;
+            h->n_raw += c->n_records - h->n_records + merged;
             h->n_records = c->n_records;
             break;
         }
@@ -624,6 +640,7 @@ int ipx_clear(ipx_handle *h) {
     if (!h) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
     h->n_records = 0;
+    h->n_raw = 0;
     h->n_alignments = 0;
     h->digs_stale = false;
     memset(&h->table, 0, sizeof h->table);
@@ -768,7 +785,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             g.seq_len = h->d_seq_len.as<int64_t>(); g.seq_word2 = h->d_seq_word2.as<uint64_t>();
             g.seq_wordm = h->d_seq_wordm.as<uint64_t>(); g.seq_of_rank = h->d_seq_of_rank.as<int32_t>();
         }
-        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->key, rb, g, sj_filter,
+        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));
         if ((rc = read_back(h, small, rb.totals, 8, h->counters.p, sizeof(Counters) / 4))) return rc;
@@ -823,7 +840,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
     t.n_junctions = n_valid;
     t.n_hist = n_hist;
     t.n_alignments = h->n_alignments;
-    t.n_records = R;
+    t.n_records = h->n_raw;
     t.memory = memory;
     if (memory == IPX_MEM_DEVICE || R == 0) {
         t.target = rb.out_target; t.intron_start = rb.out_intron_start; t.intron_end = rb.out_intron_end;
@@ -1039,6 +1056,8 @@ int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64
     *n_records = n;
     if (n == 0) return IPX_OK;
     if (!dst || capacity < n) return IPX_EINVAL;
+    if (h->n_raw != n)
+        return fail(h, IPX_EINVAL, "ipx_records_export: records were combined; set IPX_OPT_COMBINE to 0 before the first push%s%ld", "", 0);
     std::vector<uint32_t> items(4 * n), pays(4 * n);
     HIPCHK(hipMemcpyAsync(items.data(), h->items_a.p, n * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pays.data(), h->pays.p, n * 16, hipMemcpyDeviceToHost, h->stream));
@@ -1088,7 +1107,7 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
     ProfScope prof_scope(&h->prof);
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     HIPCHK(hipMemcpyAsync(d_spl, host, sizeof host, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(ipx_launch_partition(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->n_records, h->key, n_parts,
+    HIPCHK(ipx_launch_partition(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->n_records, h->key, n_parts,
                                 d_spl, d_blk, d_cnt, (uint4 *)dst_records));
     if ((rc = read_back(h, h->pin_small, d_cnt, 64 * 2))) return rc;
     h->prof.collect();
@@ -1100,24 +1119,52 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
 int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n_alignments) {
     if (!h || (n && !records)) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
-    // the handle's own records are replaced
+    // the handle's own records are replaced; what its scan found wrong with the input stays (err_word):
+    // the records this rank scanned went to their key-range owners, their errors did not
+    const unsigned long long scan_err = h->err_word_host;
     h->n_records = 0;
+    h->n_raw = 0;
     h->digs_stale = false;
     h->first_window = h->first_hint;
     int rc = reset_counters(h);
     if (rc) return rc;
+    if (scan_err != IPX_ERRW_NONE) {
+        Counters c{};
+        c.n_records = 0;
+        c.err_word = scan_err;
+        for (int k = 0; k < 3; ++k) { c.key_or[k] = 0; c.key_and[k] = ~0u; }
+        hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), c);
+        HIPCHK(hipGetLastError());
+        h->err_word_host = scan_err;
+    }
     if ((rc = grow_records(h, n))) return rc;
     ProfScope prof_scope(&h->prof);
     ipx_prof_mark(h->stream, IPXK_BEGIN);
+    unsigned long long *merged_dev = reinterpret_cast<unsigned long long *>(h->counters.as<char>() + IPX_CNT_MERGED);
+    HIPCHK(hipMemsetAsync(merged_dev, 0, sizeof(unsigned long long), h->stream));
     HIPCHK(ipx_launch_adopt(h->stream, (const uint4 *)records, n, 0, h->items_a.as<uint4>(), h->pays.as<uint4>(),
-                            h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>()));
-    if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
+                            h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>()));
+    if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, merged_dev, 2))) return rc;
     h->prof.collect();
     const Counters *c = (const Counters *)h->pin_small;
+    const uint32_t *m2 = (const uint32_t *)h->pin_small + sizeof(Counters) / 4;
     for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
     h->n_records = n;
+    h->n_raw = n + ((uint64_t)m2[0] | ((uint64_t)m2[1] << 32));
     h->n_alignments = n_alignments;
     return IPX_OK;
+}
+
+int ipx_set_option(ipx_handle *h, int32_t option, int64_t value) {
+    if (!h) return IPX_EINVAL;
+    switch (option) {
+        case IPX_OPT_COMBINE:
+            if (h->n_records) return fail(h, IPX_EINVAL, "ipx_set_option(IPX_OPT_COMBINE) with records pending%s%ld", "", 0);
+            h->opt_combine = value != 0;
+            return IPX_OK;
+        default:
+            return fail(h, IPX_EINVAL, "ipx_set_option: unknown option %s%ld", "", (long)option);
+    }
 }
 
 int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes) {

@@ -28,6 +28,17 @@
 //   strand = the READ's junction strand (junctions_extractor.cc:362-371)
 //   cat    = ReadCategory (junctions.hh:49-53) or 3 = get_read_category would
 //            throw (junctions_extractor.cc:73-74)
+//
+// Next to the two halves every record has a 4-byte count word (cnts[], indexed like pays[]):
+//   c0 | c1 << 10 | c2 << 20 = how many reads of category 0/1/2 the record stands for.
+// A record straight from a CIGAR has one bit set (none when cat == 3).  The short-read scan COMBINES
+// the records of a tile that share the whole 96-bit key (same junction, same read offset) before they
+// leave the LDS pool -- a coordinate-sorted pile-up on a hot junction hands the sort one record per
+// (junction, offset) and tile instead of hundreds: order64 = the smallest of the group (with that
+// record's strand), anchors = min / max, counts = sums.  See k_scan_short.
+#define IPX_CNT_BITS 10
+#define IPX_CNT_MASK 0x3ffu
+#define IPX_CNT_ONE(cat) ((cat) < 3u ? (1u << (IPX_CNT_BITS * (cat))) : 0u)
 #define IPX_ORD_SHIFT_READ 30
 #define IPX_ORD_SHIFT_ORDINAL 10
 #define IPX_ORD_MAX_ORDINAL ((1u << 20) - 1)
@@ -71,14 +82,17 @@ struct ScanParams {
     // closes the gaps the stripes leave, so everybody else sees base + n dense records.
     uint64_t base;
     uint32_t n_stripes;
+    // 1: k_scan_short combines equal-key records of a tile (off when the caller wants every record:
+    // ipx_records_export, or when a record may fail the junction filter -- see ipx_push_batch)
+    uint32_t combine;
 };
 constexpr uint32_t IPX_STRIPES = 8;
 constexpr uint32_t IPX_STRIPE_CHUNK_BITS = 11;       // 2048 records: stripe s owns chunks s, s + 8, s + 16, ...
 // The Counters allocation (2 KiB): Counters at 0, the copy of the CIGAR array's tail at 128 (ipx_scan.hip),
 // stripe counters at 256 + 128 * s, gap-closing counters at 1280 / 1408, length of the list of alignments
-// k_scan_short leaves to k_scan_rest at 1536.
+// k_scan_short leaves to k_scan_rest at 1536, number of records the tile combiner merged into others at 1544.
 constexpr uint32_t IPX_COUNTERS_BYTES = 2048, IPX_CNT_TAIL = 128, IPX_CNT_STRIPE0 = 256, IPX_CNT_CLOSE = 1280,
-                   IPX_CNT_DEFER = 1536;
+                   IPX_CNT_DEFER = 1536, IPX_CNT_MERGED = 1544;
 
 // device-side counters of one handle (one cache line apart is not needed: they
 // are touched once per wave at most)
@@ -210,19 +224,19 @@ void ipx_prof_pre(hipStream_t s, int id);
 // p.n_stripes / p.base are set by the launcher (striped when the grid is large and close_ws is given;
 // close_ws: room for 2 * close_cap 64-bit entries; defer: room for one uint32 per alignment of the batch)
 hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
-                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
+                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
                            unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer);
 // second stage after a short-CIGAR launch whose counters show n_defer > 0 listed alignments (IPX_CNT_DEFER)
 hipError_t ipx_launch_scan_rest(hipStream_t s, ScanParams p, const ipx_batch &b, const uint32_t *rank_of_tid,
-                                uint4 *items, uint4 *pays, uint8_t *digs, uint64_t capacity, Counters *counters,
+                                uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs, uint64_t capacity, Counters *counters,
                                 uint64_t n_records_before, unsigned long long *close_ws, uint64_t close_cap,
                                 const uint32_t *defer, uint32_t n_defer);
 
 // ipx_scan_ops.hip: the same scan with one lane per CIGAR operation (needs back-to-back CIGAR
 // words; raises Counters::pad[0] otherwise and the caller re-runs ipx_launch_scan)
 hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_batch &b,
-                               const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
+                               const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs,
                                uint64_t capacity, Counters *counters);
 
 // ipx_sort.hip
@@ -245,12 +259,13 @@ hipError_t ipx_launch_scan_u32_pair(hipStream_t s, const uint32_t *in1, uint32_t
 hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
                              uint32_t n_samples, unsigned long long *out /* device */);
 uint32_t ipx_partition_blocks(uint64_t n);
-// count, plan and scatter in one go: the records (item, payload pairs) of part p end up one after the
-// other in out_records, parts in order; totals (device, 64 words) receives the part sizes.
+// count, plan and scatter in one go: the records (item, payload pairs; the item's fourth word carries the
+// record's count word on the way) of part p end up one after the other in out_records, parts in order;
+// totals (device, 64 words) receives the part sizes.
 // blk: device scratch, 64 words per block of ipx_partition_blocks(n)
-hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
+hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *pays, const uint32_t *cnts, uint64_t n,
                                 const KeyLayout &kl, uint32_t n_parts,
                                 const unsigned long long *splitters /* device */, unsigned long long *blk,
                                 unsigned long long *totals, uint4 *out_records);
 hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
-                            uint4 *pays, uint8_t *digs, DigitSpec first, Counters *counters);
+                            uint4 *pays, uint32_t *cnts, uint8_t *digs, DigitSpec first, Counters *counters);

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(1024) void k_part_plan(unsigned long long *__restri
 }
 
 __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ items, const uint4 *__restrict__ pays,
+                                                      const uint32_t *__restrict__ cnts,
                                                       uint64_t n, KeyLayout kl, uint32_t n_parts,
                                                       const unsigned long long *__restrict__ spl_g,
                                                       const unsigned long long *__restrict__ blk,
@@ -139,8 +140,11 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ 
                 todo &= ~m;
             }
             if (ok) {
+                // on the way the item's fourth word (the record index, meaningless elsewhere) carries the count word
+                const uint4 py = pays[it.w];
+                it.w = cnts[it.w];
                 out[2 * pos] = it;
-                out[2 * pos + 1] = pays[it.w];
+                out[2 * pos + 1] = py;
             }
         }
     }
@@ -150,12 +154,17 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ 
 // OR/AND of the keys
 __global__ __launch_bounds__(256) void k_adopt(const uint4 *__restrict__ rec, uint64_t n, uint64_t first_index,
                                                uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                               uint32_t *__restrict__ cnts,
                                                uint8_t *__restrict__ digs, DigitSpec first, Counters *counters) {
     __shared__ uint32_t kb_s[4][6];
     uint32_t v[6] = {0u, 0u, 0u, ~0u, ~0u, ~0u};
+    unsigned long long extra = 0;             // reads the records stand for beyond one each (combined records)
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         uint4 it = rec[2 * i];
         const uint64_t idx = first_index + i;
+        cnts[idx] = it.w;
+        const uint32_t reads = (it.w & IPX_CNT_MASK) + ((it.w >> IPX_CNT_BITS) & IPX_CNT_MASK) + (it.w >> (2 * IPX_CNT_BITS));
+        extra += reads ? reads - 1u : 0u;
         it.w = (uint32_t)idx;
         items[idx] = it;
         pays[idx] = rec[2 * i + 1];
@@ -164,6 +173,9 @@ __global__ __launch_bounds__(256) void k_adopt(const uint4 *__restrict__ rec, ui
         v[3] &= it.x; v[4] &= it.y; v[5] &= it.z;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int d = 32; d >= 1; d >>= 1) extra += __shfl_xor(extra, d);
+    if (lane == 0 && extra)
+        atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED), extra);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         for (int d = 32; d >= 1; d >>= 1) {
@@ -202,7 +214,7 @@ uint32_t ipx_partition_blocks(uint64_t n) {
 }
 
 // blk: MAX_PARTS (64) words per block of ipx_partition_blocks(n); totals: 64 words
-hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *pays, uint64_t n,
+hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *pays, const uint32_t *cnts, uint64_t n,
                                 const KeyLayout &kl, uint32_t n_parts, const unsigned long long *splitters,
                                 unsigned long long *blk, unsigned long long *totals, uint4 *out_records) {
     if (n_parts > MAX_PARTS) return hipErrorInvalidValue;
@@ -210,18 +222,18 @@ hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *
     hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(256), 0, s, items, n, kl, n_parts, splitters, blk);
     hipLaunchKernelGGL(k_part_plan, dim3(1), dim3(1024), 0, s, blk, blocks, n_parts, totals);
     if (n)
-        hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(256), 0, s, items, pays, n, kl, n_parts, splitters, blk,
+        hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(256), 0, s, items, pays, cnts, n, kl, n_parts, splitters, blk,
                            out_records);
     ipx_prof_mark(s, IPXK_PARTITION);
     return hipGetLastError();
 }
 
 hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uint64_t first_index, uint4 *items,
-                            uint4 *pays, uint8_t *digs, DigitSpec first, Counters *counters) {
+                            uint4 *pays, uint32_t *cnts, uint8_t *digs, DigitSpec first, Counters *counters) {
     if (!n) return hipSuccess;
     uint64_t blocks = ipx_div_up(n, 2048);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adopt, dim3((uint32_t)blocks), dim3(256), 0, s, records, n, first_index, items, pays, digs,
+    hipLaunchKernelGGL(k_adopt, dim3((uint32_t)blocks), dim3(256), 0, s, records, n, first_index, items, pays, cnts, digs,
                        first, counters);
     ipx_prof_mark(s, IPXK_ADOPT);
     return hipGetLastError();

@@ -32,7 +32,7 @@ struct ReduceBuffers {
 
 uint64_t ipx_reduce_chunks(uint64_t n);
 hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b);
-hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const KeyLayout &kl,
+hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const uint32_t *cnts, const KeyLayout &kl,
                              const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters);
 hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *sorted_rank_items, uint32_t *ijunc);

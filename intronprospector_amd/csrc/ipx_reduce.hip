@@ -215,6 +215,7 @@ struct MinU64 { __device__ unsigned long long operator()(unsigned long long a, u
 struct MinU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; } };
 struct MaxU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 struct AddU32 { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+struct AddU64 { __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
 
 // ---- the reduce kernel ---------------------------------------------------------------
 // MODE 0  no record can fail the filter: creator = first = min order, everything counted
@@ -291,6 +292,7 @@ __device__ __forceinline__ JAcc bcast_acc(const JAcc &x, int src) {
 template <int MODE>
 __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
                                                 const uint4 *__restrict__ pays,
+                                                const uint32_t *__restrict__ cnts,
                                                 const uint32_t *__restrict__ chunk_j,
                                                 const uint32_t *__restrict__ chunk_b,
                                                 const uint32_t *__restrict__ jmotif, int32_t sj_filter,
@@ -335,6 +337,8 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
         unsigned long long poison = NONE64;
         if (h.ok) {
             const uint4 p = pays[h.it.w];
+            // reads per category this record stands for (one, unless the scan combined a tile's copies of it)
+            const uint32_t cw = (MODE != 1) ? cnts[h.it.w] : 0u;
             const unsigned long long ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
             bool cnt_it = true;
             if (MODE == 1) {
@@ -349,10 +353,10 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
                 v.m2 = NONE64;            // MODE 0: the creator is m1
             }
             if (cnt_it) {
-                counted = 1;
                 const uint32_t cat = IPX_ORD_CAT(ord);
                 if (cat == 3) poison = (ord & ~0x3ffull) | (IPX_ERRK_CATEGORY << 8);   // junctions_extractor.cc:73-74
-                v.c0 = cat == 0; v.c1 = cat == 1; v.c2 = cat == 2;
+                v.c0 = cw & IPX_CNT_MASK; v.c1 = (cw >> IPX_CNT_BITS) & IPX_CNT_MASK; v.c2 = cw >> (2 * IPX_CNT_BITS);
+                counted = v.c0 + v.c1 + v.c2;
                 v.lo = p.z;
                 v.hi = p.w;
             }
@@ -366,9 +370,10 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
             if (MODE != 0) v.m2 = seg_reduce(v.m2, lane, last_j, MinU64());          // MODE 0: first == creator, m2 is dead
         }
         if (MODE != 1) {
-            uint32_t cpk = v.c0 | (v.c1 << 8) | (v.c2 << 16);          // <= 64 per field and round
-            cpk = seg_reduce(cpk, lane, last_j, AddU32());
-            v.c0 = cpk & 0xffu; v.c1 = (cpk >> 8) & 0xffu; v.c2 = (cpk >> 16) & 0xffu;
+            // <= 64 * 1023 per field and round
+            unsigned long long cpk = (unsigned long long)v.c0 | ((unsigned long long)v.c1 << 16) | ((unsigned long long)v.c2 << 32);
+            cpk = seg_reduce(cpk, lane, last_j, AddU64());
+            v.c0 = (uint32_t)cpk & 0xffffu; v.c1 = (uint32_t)(cpk >> 16) & 0xffffu; v.c2 = (uint32_t)(cpk >> 32);
             v.lo = seg_reduce(v.lo, lane, last_j, MinU32());
             v.hi = seg_reduce(v.hi, lane, last_j, MaxU32());
         }
@@ -666,7 +671,7 @@ hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t
     return hipGetLastError();
 }
 
-hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const KeyLayout &kl,
+hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const uint32_t *cnts, const KeyLayout &kl,
                              const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters) {
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
@@ -691,14 +696,14 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
     if (!filter_active) {
         ipx_prof_pre(s, IPXK_PHASE_B);
-        hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
+        hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
                            rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters);
         ipx_prof_mark(s, IPXK_PHASE_B);
     } else {
-        hipLaunchKernelGGL(k_reduce<1>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
+        hipLaunchKernelGGL(k_reduce<1>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
                            rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
         ipx_prof_mark(s, IPXK_PHASE_A);
-        hipLaunchKernelGGL(k_reduce<2>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, rb.chunk_j, rb.chunk_b,
+        hipLaunchKernelGGL(k_reduce<2>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
                            rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
         ipx_prof_mark(s, IPXK_PHASE_B);
     }

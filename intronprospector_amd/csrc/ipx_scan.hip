@@ -136,12 +136,14 @@ __device__ __forceinline__ void pack_record_rel(const ScanParams &p, const ReadC
 
 __device__ __forceinline__ void store_record(const ScanParams &p, const ReadCtx &c, const Rec &r,
                                              uint32_t ordinal, uint64_t idx, uint4 *__restrict__ items,
-                                             uint4 *__restrict__ pays, uint8_t *__restrict__ digs, KeyBits &kb) {
+                                             uint4 *__restrict__ pays, uint32_t *__restrict__ cnts,
+                                             uint8_t *__restrict__ digs, KeyBits &kb) {
     uint4 it, pay;
     pack_record(p, c, r, ordinal, it, pay);
     it.w = (uint32_t)idx;
     items[idx] = it;
     pays[idx] = pay;
+    cnts[idx] = IPX_CNT_ONE(c.cat);
     digs[idx] = (uint8_t)ipx_digit_of(it, p.first);  // digit of the first sort pass
     kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
     kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
@@ -157,6 +159,7 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
                                              const uint32_t *__restrict__ cig, uint32_t nc,
                                              uint64_t slot0, uint64_t capacity,
                                              uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                             uint32_t *__restrict__ cnts,
                                              uint8_t *__restrict__ digs, KeyBits &kb,
                                              unsigned long long &err,
                                              unsigned long long *n_records = nullptr, uint32_t stripe = 0) {
@@ -169,11 +172,11 @@ __device__ __forceinline__ uint32_t run_read(const ScanParams &p, const ReadCtx 
         if (qc_pass(p, c, r)) {
             if (MODE == 1) {
                 const uint64_t idx = append_index(p, stripe, slot0 + ordinal);
-                if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
+                if (idx < capacity && ordinal <= IPX_ORD_MAX_ORDINAL) store_record(p, c, r, ordinal, idx, items, pays, cnts, digs, kb);
             } else if (MODE == 3) {
                 if (ordinal >= slot0 && ordinal <= IPX_ORD_MAX_ORDINAL) {
                     const uint64_t idx = append_index(p, stripe, atomicAdd(n_records, 1ull));
-                    if (idx < capacity) store_record(p, c, r, ordinal, idx, items, pays, digs, kb);
+                    if (idx < capacity) store_record(p, c, r, ordinal, idx, items, pays, cnts, digs, kb);
                 }
             }
             ++ordinal;
@@ -285,11 +288,12 @@ struct __attribute__((packed, aligned(4))) Words4 { uint32_t x, y, z, w; };
 // that would reach past the end of the array reads here instead
 // (also starts the launch's list of deferred alignments at zero, see k_scan_rest)
 __global__ void k_cigar_tail(const uint32_t *__restrict__ cigar, uint64_t n_words, uint32_t *__restrict__ tail,
-                             uint32_t *__restrict__ defer_n) {
+                             uint32_t *__restrict__ defer_n, unsigned long long *__restrict__ merged_n) {
     const uint32_t t = threadIdx.x;
     const uint64_t tb = n_words >= 8 ? n_words - 8 : 0;
     if (t < 16) tail[t] = (tb + t < n_words) ? cigar[tb + t] : 0u;
     if (t == 16) *defer_n = 0;
+    if (t == 17) *merged_n = 0;
 }
 
 // four words starting at word w of the CIGAR array (w < n_words); only the address is selected
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
                                                    const uint32_t *__restrict__ tail,
                                                    const uint32_t *__restrict__ rank_of_tid,
                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                   uint8_t *__restrict__ digs,
+                                                   uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
                                                    uint64_t capacity, Counters *counters) {
     __shared__ uint4 pool_item[4][LONG_POOL], pool_pay[4][LONG_POOL];
     __shared__ LongStage stage_s[4];
@@ -347,7 +351,9 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
                 uint4 it = my_item[k];
                 it.w = (uint32_t)idx;
                 items[idx] = it;
-                pays[idx] = my_pay[k];
+                const uint4 py = my_pay[k];
+                pays[idx] = py;
+                cnts[idx] = IPX_CNT_ONE(py.x & 3u);
                 digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
                 kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                 kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
                 c.pos = (int32_t)pos32; c.flag = 0; c.nhc = 0; c.rank = rank;
                 c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
                 c.read_index = base_read_index + my_i;
-                (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, digs, kb,
+                (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, cnts, digs, kb,
                                   my_err, append_counter(counters, p, stripe), stripe);
                 redo = false;
             }
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                                                     const uint32_t *__restrict__ tail,
                                                     const uint32_t *__restrict__ rank_of_tid,
                                                     uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                    uint8_t *__restrict__ digs,
+                                                    uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
                                                     uint64_t capacity, Counters *counters,
                                                     uint32_t *__restrict__ defer) {
     constexpr uint32_t NW = BT / 64;                 // waves per block
@@ -706,6 +712,14 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     __shared__ uint32_t pool_n;
     __shared__ uint16_t cx_list[BT * RPT];       // tile-local indices of the alignments that need the walk
     __shared__ uint32_t cx_n;
+    // the tile combiner (ScanParams::combine): open-addressing table of pool indices, one per distinct key
+    constexpr uint32_t HT_BITS = POOL > 384 ? 10 : (POOL > 192 ? 9 : 8), HT = 1u << HT_BITS;   // >= 4/3 POOL
+    constexpr uint32_t CR = (POOL + BT - 1) / BT;                                              // pool rounds per thread
+    constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DEAD = 0xffffffffu;
+    static_assert(HT * 3 >= POOL * 4 && POOL <= IPX_CNT_MASK, "combiner table / count word too small for the pool");
+    __shared__ uint32_t ht[HT];
+    __shared__ uint32_t live_n[CR][NW];
+    unsigned long long merged_acc = 0;            // thread 0: records merged into others by this block
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + (uint64_t)BT * RPT - 1) / ((uint64_t)BT * RPT);
     const uint32_t stripe = my_stripe(p);
@@ -725,6 +739,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         unsigned long long my_err = IPX_ERRW_NONE;
         if (t == 0) { pool_n = 0; cx_n = 0; }
+        if (p.combine)
+            for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
         __syncthreads();
         // Phase 1, every alignment of the tile: the plain spliced reads "aM nN bM" (two thirds of short-read data)
         // and "aM nN bM nN cM" (most of the rest) have closed forms -- one or two junctions, anchors a, b, c, no
@@ -929,7 +945,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         }
         __syncthreads();
         const uint32_t total = pool_n;
-        if (total <= POOL) {
+        if (total <= POOL && !p.combine) {
             if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;
@@ -937,6 +953,127 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 const uint64_t idx = append_index(p, stripe, slot + k);
                 if (idx < capacity) {
                     uint4 it = pool_item[k];
+                    it.w = (uint32_t)idx;
+                    items[idx] = it;
+                    const uint4 py = pool_pay[k];
+                    pays[idx] = py;
+                    cnts[idx] = IPX_CNT_ONE(py.x & 3u);
+                    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+                }
+            }
+        } else if (total <= POOL) {
+            // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
+            // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
+            // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
+            // exchange) then handles one record per key and tile.  What a group keeps is what the reduce would
+            // have made of its members anyway: the smallest order64 (with that record's strand), the smallest
+            // anchor start, the largest anchor end, the reads per category (item.w, IPX_CNT_*; it is 0 in the
+            // pool).  The first record of a key to claim a table slot OWNS the group, the others add themselves
+            // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
+            // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
+            // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
+#pragma unroll 1
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                bool live = k < total;
+                uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);
+                if (live) { it = pool_item[k]; py = pool_pay[k]; }
+                const uint32_t cat = py.x & 3u;
+                live = live && cat != 3u;
+                unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
+                uint32_t lo = py.z, hi = py.w, cw = IPX_CNT_ONE(cat);
+                bool dead = false;
+                const unsigned long long lm = ipx_ballot(live);
+                if (lm) {
+                    const int f = __ffsll(lm) - 1;
+                    const uint32_t fx = __builtin_amdgcn_readlane(it.x, f), fy = __builtin_amdgcn_readlane(it.y, f),
+                                   fz = __builtin_amdgcn_readlane(it.z, f);
+                    const bool same = live && it.x == fx && it.y == fy && it.z == fz;
+                    const unsigned long long sm = ipx_ballot(same);
+                    if (__popcll(sm) >= 8) {
+                        unsigned long long o = same ? ord : ~0ull;
+                        uint32_t l = same ? lo : ~0u, h = same ? hi : 0u;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) {
+                            const unsigned long long o2 = __shfl_xor(o, d);
+                            const uint32_t l2 = __shfl_xor(l, d), h2 = __shfl_xor(h, d);
+                            o = o2 < o ? o2 : o;
+                            l = l2 < l ? l2 : l;
+                            h = h2 > h ? h2 : h;
+                        }
+                        const uint32_t c0 = (uint32_t)__popcll(ipx_ballot(same && cat == 0u)),
+                                       c1 = (uint32_t)__popcll(ipx_ballot(same && cat == 1u)),
+                                       c2 = (uint32_t)__popcll(ipx_ballot(same && cat == 2u));
+                        if ((int)lane == f) {
+                            ord = o; lo = l; hi = h;
+                            cw = c0 | (c1 << IPX_CNT_BITS) | (c2 << (2 * IPX_CNT_BITS));
+                        } else if (same) {
+                            live = false;
+                            dead = true;
+                        }
+                    }
+                }
+                if (live) {
+                    uint32_t hs = it.x * 0x9E3779B1u;
+                    hs ^= it.y * 0x85EBCA77u;
+                    hs ^= it.z * 0xC2B2AE3Du;
+                    hs ^= hs >> 15;
+                    hs = (hs * 0x2C1B3C6Du) >> (32 - HT_BITS);
+                    uint32_t owner = k;
+                    for (;;) {
+                        const uint32_t o = atomicCAS(&ht[hs], HT_EMPTY, k);
+                        if (o == HT_EMPTY) break;                                   // the slot is mine: I own the key
+                        const uint4 ko = pool_item[o];
+                        if (ko.x == it.x && ko.y == it.y && ko.z == it.z) { owner = o; break; }
+                        hs = (hs + 1u) & (HT - 1u);
+                    }
+                    atomicAdd(&pool_item[owner].w, cw);
+                    atomicMin(reinterpret_cast<unsigned long long *>(&pool_pay[owner]), ord);
+                    atomicMin(&pool_pay[owner].z, lo);
+                    atomicMax(&pool_pay[owner].w, hi);
+                    dead = owner != k;
+                }
+                if (dead) pool_item[k].w = REC_DEAD;       // nobody adds to a record that owns nothing
+            }
+            __syncthreads();
+            // survivors close ranks: position = survivors before it in pool order
+            uint32_t pos_r[CR];
+            bool live_r[CR];
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                live_r[r] = k < total && pool_item[k].w != REC_DEAD;
+                const unsigned long long m = ipx_ballot(live_r[r]);
+                pos_r[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (lane == 0) live_n[r][wave] = (uint32_t)__popcll(m);
+            }
+            __syncthreads();
+            uint32_t n_out = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r)
+#pragma unroll
+                for (uint32_t w = 0; w < NW; ++w) {
+                    const uint32_t c = live_n[r][w];
+#pragma unroll
+                    for (uint32_t r2 = 0; r2 < CR; ++r2)
+                        if (r < r2 || (r == r2 && w < wave)) pos_r[r2] += c;
+                    n_out += c;
+                }
+            if (t == 0) {
+                tile_slot = n_out ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)n_out) : 0ull;
+                merged_acc += total - n_out;
+            }
+            __syncthreads();
+            const uint64_t slot = tile_slot;
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                const uint64_t idx = append_index(p, stripe, slot + pos_r[r]);
+                if (live_r[r] && idx < capacity) {
+                    uint4 it = pool_item[k];
+                    cnts[idx] = it.w;
                     it.w = (uint32_t)idx;
                     items[idx] = it;
                     pays[idx] = pool_pay[k];
@@ -983,6 +1120,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
         __syncthreads();
     }
+    if (t == 0 && merged_acc)
+        atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED), merged_acc);
     uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -1012,7 +1151,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, const uint32_t *__restrict__ cigar,
                                                    const uint32_t *__restrict__ defer,
                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                   uint8_t *__restrict__ digs, uint64_t capacity, Counters *counters) {
+                                                   uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
+                                                   uint64_t capacity, Counters *counters) {
     const uint32_t n_def = *defer_counter(counters);
     if (n_def == 0) return;
     __shared__ uint32_t kb_s[4][6];
@@ -1028,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, co
         uint32_t nc = 0, off = 0;
         load_read_ctx(p, a, i, c, nc, off, my_err);
         if (!mine) nc = 0;
-        const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, kb, my_err) : 0;
+        const uint32_t cn = nc ? run_read<0>(p, c, cigar + off, nc, 0, 0, nullptr, nullptr, nullptr, nullptr, kb, my_err) : 0;
         uint32_t incl = cn;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1041,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, co
         slot = __shfl(slot, 63);
         if (cn) {
             unsigned long long dummy = IPX_ERRW_NONE;
-            (void)run_read<1>(p, c, cigar + off, nc, slot + (incl - cn), capacity, items, pays, digs, kb, dummy,
+            (void)run_read<1>(p, c, cigar + off, nc, slot + (incl - cn), capacity, items, pays, cnts, digs, kb, dummy,
                               nullptr, stripe);
         }
     }
@@ -1144,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_close_move(const Counters *counters, ui
                                                     const unsigned long long *__restrict__ holes,
                                                     const unsigned long long *__restrict__ tails, uint64_t list_cap,
                                                     uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                    uint8_t *__restrict__ digs) {
+                                                    uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs) {
     const unsigned long long n = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(counters) + IPX_CNT_CLOSE);
     if (n > list_cap) return;                       // reported by k_close_finish
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1153,6 +1293,7 @@ __global__ __launch_bounds__(256) void k_close_move(const Counters *counters, ui
         it.w = (uint32_t)dst;
         items[dst] = it;
         pays[dst] = pays[src];
+        cnts[dst] = cnts[src];
         digs[dst] = digs[src];
     }
 }
@@ -1173,7 +1314,7 @@ __global__ void k_close_finish(Counters *counters, uint64_t base, uint64_t capac
 }  // namespace
 
 hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
-                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint8_t *digs,
+                           const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
                            unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer) {
     if (b.n_alignments == 0) return hipSuccess;
@@ -1208,7 +1349,8 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     ipx_prof_pre(s, IPXK_SCAN);
     hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail,
-                       reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_DEFER));
+                       reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_DEFER),
+                       reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED));
     // stripes pay once many blocks queue on the record counter
     static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
     p.base = n_records_before;
@@ -1216,15 +1358,15 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     if (short_reads && short_bt == 256)
         hipLaunchKernelGGL((k_scan_short<2, 768, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
+                           b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
     else if (short_reads && short_bt == 64)
         hipLaunchKernelGGL((k_scan_short<2, 192, 64>), dim3((uint32_t)blocks), dim3(64), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
+                           b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
     else if (short_reads)
         hipLaunchKernelGGL((k_scan_short<2, 384, 128>), dim3((uint32_t)blocks), dim3(128), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters, defer);
+                           b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
     else {
         // long CIGARs: waves work through ranges of >= 64 alignments
         static const uint32_t min_range = [] {
@@ -1241,12 +1383,12 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         p.n_stripes = (waves >= 256 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
         hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
-                           b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, digs, capacity, counters);
+                           b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
     }
     if (p.n_stripes) {
         unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
         hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);
-        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, digs);
+        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, cnts, digs);
         hipLaunchKernelGGL(k_close_finish, dim3(1), dim3(64), 0, s, counters, p.base, capacity, close_cap);
     }
     ipx_prof_mark(s, IPXK_SCAN);
@@ -1256,7 +1398,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
 // Second stage of a short-CIGAR scan: the n_defer alignments the first stage listed in defer[] (the caller read
 // the count back with the launch's counters; most launches list none and never get here).
 hipError_t ipx_launch_scan_rest(hipStream_t s, ScanParams p, const ipx_batch &b, const uint32_t *rank_of_tid,
-                                uint4 *items, uint4 *pays, uint8_t *digs, uint64_t capacity, Counters *counters,
+                                uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs, uint64_t capacity, Counters *counters,
                                 uint64_t n_records_before, unsigned long long *close_ws, uint64_t close_cap,
                                 const uint32_t *defer, uint32_t n_defer) {
     if (n_defer == 0) return hipSuccess;
@@ -1267,12 +1409,12 @@ hipError_t ipx_launch_scan_rest(hipStream_t s, ScanParams p, const ipx_batch &b,
     const AlnArrays aln{b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar, rank_of_tid,
                         b.n_alignments, b.n_cigar_words, b.base_read_index};
     ipx_prof_pre(s, IPXK_SCAN);
-    hipLaunchKernelGGL(k_scan_rest, dim3(blocks), dim3(256), 0, s, p, aln, b.cigar, defer, items, pays, digs, capacity,
+    hipLaunchKernelGGL(k_scan_rest, dim3(blocks), dim3(256), 0, s, p, aln, b.cigar, defer, items, pays, cnts, digs, capacity,
                        counters);
     if (p.n_stripes) {
         unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
         hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);
-        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, digs);
+        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, cnts, digs);
         hipLaunchKernelGGL(k_close_finish, dim3(1), dim3(64), 0, s, counters, p.base, capacity, close_cap);
     }
     ipx_prof_mark(s, IPXK_SCAN);

@@ -55,6 +55,7 @@ struct OpsArgs {
     uint32_t reads_per_wave;
     uint4 *__restrict__ items;
     uint4 *__restrict__ pays;
+    uint32_t *__restrict__ cnts;
     uint8_t *__restrict__ digs;
     uint64_t capacity;
     Counters *counters;
@@ -335,6 +336,7 @@ __device__ __forceinline__ uint32_t wave_span(const OpsArgs &a, uint64_t ra, uin
                 const uint4 it = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)idx);
                 a.items[idx] = it;
                 a.pays[idx] = make_uint4((uint32_t)order, (uint32_t)(order >> 32), r_pos + r_as, r_pos + r_ae);
+                a.cnts[idx] = IPX_CNT_ONE((uint32_t)order & 3u);
                 a.digs[idx] = (uint8_t)ipx_digit_of(it, a.p.first);
                 kb[0] |= (uint32_t)lo; kb[1] |= (uint32_t)(lo >> 32); kb[2] |= (uint32_t)hi;
                 kb[3] &= (uint32_t)lo; kb[4] &= (uint32_t)(lo >> 32); kb[5] &= (uint32_t)hi;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_scan_ops(OpsArgs a) {
 }  // namespace
 
 hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_batch &b, const uint32_t *rank_of_tid,
-                               uint4 *items, uint4 *pays, uint8_t *digs, uint64_t capacity, Counters *counters) {
+                               uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs, uint64_t capacity, Counters *counters) {
     if (b.n_alignments == 0) return hipSuccess;
     OpsArgs a{};
     a.p = p;
@@ -456,7 +458,7 @@ hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_bat
     if (rpw < 1) rpw = 1;
     if (rpw > 2048) rpw = 2048;
     a.reads_per_wave = (uint32_t)rpw;
-    a.items = items; a.pays = pays; a.digs = digs; a.capacity = capacity; a.counters = counters;
+    a.items = items; a.pays = pays; a.cnts = cnts; a.digs = digs; a.capacity = capacity; a.counters = counters;
     const uint64_t waves = ipx_div_up(b.n_alignments, rpw);
     uint64_t blocks = ipx_div_up(waves, 4);
     if (blocks > 256ull * 32) blocks = 256ull * 32;

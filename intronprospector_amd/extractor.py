@@ -42,7 +42,7 @@ class JunctionsExtractor:
     def __init__(self, min_anchor_length=8, max_anchor_indel_size=0, min_intron_length=70,
                  max_intron_length=500000, junction_filter=L.IPX_SJ_NULL, strandness=L.IPX_UNSTRANDED,
                  excludes=0, skip_missing_targets=False, scope=L.IPX_SCOPE_TARGET, device=0,
-                 targets=(), target_lengths=None, genome=None):
+                 targets=(), target_lengths=None, genome=None, combine=True):
         self.lib = L.load()
         p = L.Params(min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length,
                      junction_filter, strandness, excludes, scope, int(bool(skip_missing_targets)), device)
@@ -54,6 +54,8 @@ class JunctionsExtractor:
         if rc:
             raise RuntimeError("ipx_create failed with status %d" % rc)
         self.h = h
+        if not combine:      # every junction record stays a record of its own (records_export)
+            self._check(self.lib.ipx_set_option(self.h, L.IPX_OPT_COMBINE, 0))
         self.next_read_index = 0
         self._keep = []
         if len(targets):

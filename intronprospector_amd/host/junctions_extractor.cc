@@ -39,6 +39,11 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
     if (rc == IPX_ENODEVICE)
         throw std::runtime_error("no MI355X (gfx950) device available: this build has no CPU path");
     if (rc != IPX_OK) throw std::runtime_error("ipx_create failed");
+    // the trace and the strand tags walk the single junction records (export_records)
+    if (trace_fh_ || set_xs_ || set_ts_) {
+        rc = ipx_set_option(h_, IPX_OPT_COMBINE, 0);
+        if (rc != IPX_OK) throw_last_error(rc);
+    }
     if (genome_) {
         const size_t n = genome_->n_seqs();
         std::vector<const char *> names(n);

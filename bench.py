@@ -5,14 +5,24 @@ A step is one pass of the path over one batch of synthetic alignments that is
 already resident in HBM: ipx_clear -> ipx_push_batch (CIGAR scan -> junction
 records) -> ipx_finalize (radix sort + segmented reduce -> junction table in
 HBM).  With N > 1 every rank holds its own contiguous shard of N x reads
-alignments (weak scaling) and the partial tables are combined over RCCL.
+alignments (weak scaling) and the partial results are combined over RCCL.
 
 Timing: W warm-up steps, then exactly K timed steps between barrier + synchronize.  Inside the timed
-region HIP events bracket the launches of the dominant kernel class only (roofline.avg_ms); the full
-per-kernel table (roofline.kernels_ms_per_step) comes from three further, untimed steps with events
-around every launch.
+region HIP events bracket the launches of the dominant kernel class only (roofline.kernel_avg_ms); the
+full per-kernel table (roofline.kernels_ms_per_step) comes from three further, untimed steps with
+events around every launch.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+What the JSON line says (rank 0 prints ONE line; DESIGN.md "Measurement"):
+  value / ms_per_step   whole-job alignments per second over the timed region (input resident in HBM)
+  roofline.frac         SURVEY 8(d): algorithmic bytes of the WHOLE step (20 + 4c + 64j per alignment)
+                        / timed step / 8 TB/s -- sort passes, heads and launch gaps all count as time
+  roofline.kernel_*     the dominant kernel alone against ITS minimum traffic (flat keys)
+  roofline.traffic      HBM bytes per step by PMC (profiles/traffic.json), waste_ratio = traffic / algorithmic
+  cpu_baseline          the oracle (a scalar port of the reference) on this host: 1 core (value) and all
+                        cores the cgroup grants (all_cores_value), host_cores / cpu_model stated
+  configs               N == 1 only: BASELINE.json's other single-GPU configurations in the same run
+                        (L: 2 M long reads, G: 10 M reads + device genome), each with ms_per_step,
+                        frac and a parity check of a prefix against the oracle
 """
 import argparse
 import json
@@ -27,6 +37,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KEYS = ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")
+DEFAULT_READS = {"S": 10_000_000, "G": 10_000_000, "L": 2_000_000}     # BASELINE.json configs[1..3]
 
 
 def make_workload(kind, reads, seed):
@@ -40,30 +52,84 @@ def make_workload(kind, reads, seed):
     raise SystemExit("unknown workload %r" % kind)
 
 
-# algorithmic bytes each kernel has to move per launch (DESIGN.md "Kernels"):
-# n alignments, w CIGAR words, r records
+# minimum bytes each kernel class has to move per launch (DESIGN.md "Kernels"):
+# n alignments, w CIGAR words, r junction records, m records after the scan's tile combiner
 KERNEL_BYTES = {
-    "k_scan": lambda n, w, r: 20 * n + 4 * w + 32 * r,     # SoA + CIGAR in, 32-byte records out
-    "k_hist": lambda n, w, r: 1 * r,                        # one digit byte per record
-    "k_scatter": lambda n, w, r: 33 * r,                    # item in, item + next digit byte out
-    "k_count_heads": lambda n, w, r: 16 * r,
-    "k_write_heads": lambda n, w, r: 16 * r,
-    "k_reduce_a": lambda n, w, r: 32 * r,                   # item + payload of every record
-    "k_reduce": lambda n, w, r: 32 * r,
+    "k_scan": lambda n, w, r, m: 20 * n + 4 * w + 36 * m,    # SoA + CIGAR in, 36-byte records out
+    "k_hist": lambda n, w, r, m: 1 * m,                      # one digit byte per record
+    "k_scatter": lambda n, w, r, m: 33 * m,                  # item in, item + next digit byte out
+    "k_count_heads": lambda n, w, r, m: 16 * m,
+    "k_write_heads": lambda n, w, r, m: 16 * m,
+    "k_reduce_a": lambda n, w, r, m: 36 * m,                 # item + payload + count word of every record
+    "k_reduce": lambda n, w, r, m: 36 * m,
 }
 
 
-def cpu_baseline(batch, names, kind, budget_reads, budget_s=10.0):
-    """The oracle (a scalar port of the reference, oracle/) timed on this host, one core: whole
-    passes over the first budget_reads alignments of the same batch (a fresh table each pass) until
-    about budget_s seconds of CPU work are done.  Reported next to the GPU number only."""
+def host_info():
+    """cores this process may use (affinity, cgroup quota) and the CPU model"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    usable = max(1, min(cores, int(quota)) if quota else cores)
+    return {"host_cores": os.cpu_count(), "affinity_cores": cores, "cgroup_cpu_quota": quota, "usable_cores": usable,
+            "cpu_model": model}
+
+
+def _oracle_params(kind):
+    return {"max_anchor_indel_size": 36} if kind == "L" else {}
+
+
+def _cpu_worker(path, lo, hi, names, params, budget_s, barrier, out_q):
+    """all-cores leg: one process per core, each over its own contiguous range of the sample"""
+    from intronprospector_amd import synth
+    from tests.oracle_binding import Oracle
+    batch = {k: np.load(os.path.join(path, k + ".npy"), mmap_mode="r") for k in KEYS}
+    shard = synth.slice_batch(batch, lo, hi)
+    barrier.wait()
+    passes, spent = 0, 0.0
+    t_start = time.perf_counter()
+    while spent < budget_s and passes < 2000:
+        ora = Oracle(targets=names, **params)
+        t0 = time.perf_counter()
+        ora.process(shard)
+        spent += time.perf_counter() - t0
+        ora.close()
+        passes += 1
+    out_q.put(((hi - lo) * passes, time.perf_counter() - t_start))
+
+
+def cpu_baseline(batch, names, kind, budget_reads, budget_s=10.0, all_cores=True):
+    """The oracle (a scalar port of the reference, oracle/) timed on this host: whole passes over the first
+    budget_reads alignments of the same batch (a fresh table each pass) until about budget_s seconds of CPU
+    work are done -- on ONE core (the reference is single-threaded), then on all cores the cgroup grants,
+    one process per core over contiguous read ranges (per-shard tables, not merged: an upper bound for a
+    threaded port).  Reported next to the GPU number only."""
     from intronprospector_amd import synth
     from tests.oracle_binding import Oracle
     n = min(budget_reads, len(batch["tid"]))
     sample = synth.slice_batch(batch, 0, n)
-    params = {"max_anchor_indel_size": 36} if kind == "L" else {}
+    params = _oracle_params(kind)
     passes, spent, nj = 0, 0.0, 0
-    while spent < budget_s and passes < 200:
+    while spent < budget_s and passes < 2000:
         ora = Oracle(targets=names, **params)
         t0 = time.perf_counter()
         ora.process(sample)
@@ -71,10 +137,212 @@ def cpu_baseline(batch, names, kind, budget_reads, budget_s=10.0):
         spent += time.perf_counter() - t0
         ora.close()
         passes += 1
-    return {"value": n * passes / spent, "unit": "alignments/s", "cores": 1, "kind": "port",
-            "sample": "%d passes over %s %d alignments of the %s workload, oracle/libipxo.so (scalar C restatement), "
-                      "%d junctions, %.1f s of CPU work" % (passes, "all" if n == len(batch["tid"]) else "the first",
-                                                            n, kind, nj, spent)}
+    info = host_info()
+    out = {"value": n * passes / spent, "unit": "alignments/s", "cores": 1, "kind": "port",
+           "sample": "%d passes over %s %d alignments of the %s workload, oracle/libipxo.so (scalar C restatement), "
+                     "%d junctions, %.1f s of CPU work" % (passes, "all" if n == len(batch["tid"]) else "the first",
+                                                           n, kind, nj, spent)}
+    out.update(info)
+    workers = info["usable_cores"]
+    if all_cores and workers > 1:
+        import multiprocessing as mp
+        import shutil
+        import tempfile
+        tmp = tempfile.mkdtemp(prefix="ipx_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            for k in KEYS:
+                np.save(os.path.join(tmp, k + ".npy"), sample[k])
+            ctx = mp.get_context("spawn")
+            barrier, q = ctx.Barrier(workers), ctx.Queue()
+            cuts = np.linspace(0, n, workers + 1).astype(int)
+            procs = [ctx.Process(target=_cpu_worker, args=(tmp, int(cuts[i]), int(cuts[i + 1]), list(names), params,
+                                                           budget_s, barrier, q)) for i in range(workers)]
+            for p in procs:
+                p.start()
+            got, deadline = [], time.time() + 20 * budget_s + 120
+            while len(got) < workers:
+                try:
+                    got.append(q.get(timeout=1.0))
+                except Exception:
+                    if any(p.exitcode not in (None, 0) for p in procs) or time.time() > deadline:
+                        for p in procs:
+                            if p.is_alive():
+                                p.terminate()
+                        raise RuntimeError("a CPU-baseline worker died or timed out")
+            for p in procs:
+                p.join(timeout=60)
+            out["all_cores"] = workers
+            out["all_cores_value"] = sum(g[0] for g in got) / max(g[1] for g in got)
+            out["all_cores_sample"] = "%d processes, one contiguous read range each, %.1f s wall, shard tables not merged" % (
+                workers, max(g[1] for g in got))
+        except Exception as e:                      # the single-core figure stands on its own
+            out["all_cores_error"] = repr(e)[:200]
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def table_digest(tab):
+    """order-free digest of a table as numpy dicts (device: extractor.get_junctions; oracle: Oracle.table)"""
+    import hashlib
+    h = hashlib.sha256()
+    order = np.lexsort((tab["intron_end"], tab["intron_start"], tab["target"].astype(np.int64)))
+    for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc"):
+        h.update(np.ascontiguousarray(tab[k][order].astype(np.int64)).tobytes())
+    h.update(np.ascontiguousarray(tab["counts"][order].astype(np.uint64)).tobytes())
+    h.update(np.ascontiguousarray(tab["offsets_flat"].astype(np.uint16)).tobytes())
+    return h.hexdigest()
+
+
+def parity_prefix(kind, batch, names, genome_pack, fasta_genome, n_prefix, device):
+    """the device path against the oracle on the first n_prefix alignments of the benchmark's own batch:
+    SHA-256 over keys, anchors, strand, ijunc, counts and the per-junction read-offset multisets"""
+    import tempfile
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth, _lib as L
+    from intronprospector_amd.extractor import expand_histogram, offsets_per_junction
+    from tests.oracle_binding import Oracle
+    n = min(n_prefix, len(batch["tid"]))
+    sample = synth.slice_batch(batch, 0, n)
+    params = _oracle_params(kind)
+    dparams, oparams, tmpdir = dict(params), dict(params), None
+    if genome_pack is not None:
+        dparams.update(genome=genome_pack, junction_filter=L.IPX_SJ_CANON)
+        tmpdir = tempfile.mkdtemp(prefix="ipx_fa_")
+        fasta = os.path.join(tmpdir, "g.fa")
+        fasta_genome.write_fasta(fasta)
+        oparams.update(genome_fasta=fasta, junction_filter=2)
+    ex = ipa.JunctionsExtractor(targets=names, device=device, **dparams)
+    ex.push(sample)
+    dev = ex.get_junctions()
+    ex.close()
+    ora = Oracle(targets=names, **oparams)
+    ora.process(sample)
+    ref = ora.table()
+    ora.close()
+    if tmpdir:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+
+    def flat_offsets(order, counts, flat):
+        starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+        return np.concatenate([flat[starts[i]:starts[i] + counts[i]] for i in order]) if len(order) else flat[:0]
+    od = np.lexsort((dev["intron_end"], dev["intron_start"], dev["target"].astype(np.int64)))
+    dev["offsets_flat"] = flat_offsets(od, offsets_per_junction(dev).astype(np.int64), expand_histogram(dev))
+    oo = np.lexsort((ref["intron_end"], ref["intron_start"], ref["target"].astype(np.int64)))
+    ref["offsets_flat"] = flat_offsets(oo, ref["n_offsets"].astype(np.int64), ref["offsets"])
+    a, b = table_digest(dev), table_digest(ref)
+    return {"alignments": n, "junctions": int(len(ref["intron_start"])), "sha256": a[:16], "equals_oracle": a == b}
+
+
+def upload(batch, dev):
+    import torch
+    arrays = [torch.from_numpy(batch[k]).to(dev) for k in KEYS]
+    torch.cuda.synchronize()
+    return arrays, [t.data_ptr() for t in arrays]
+
+
+def load_traffic(kind):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath)).get(kind, {})
+    except Exception:
+        return {}
+
+
+def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, breakdown_steps, steps):
+    c, j = n_words / n, r / n
+    b_alg = 20 + 4 * c + 64 * j                      # SURVEY.md 8(d), bytes per alignment
+    alg_step = b_alg * n
+    dev_ms = sum(v[1] for v in stats.values()) / breakdown_steps if stats else None
+    tr = load_traffic(kind)
+    traffic_step = tr.get("step_bytes")
+    out = {
+        "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "basis": "whole step: SURVEY 8(d) algorithmic bytes (20 + 4c + 64j per alignment) / timed step",
+        "achieved": alg_step / (ms_per_step * 1e-3) / 1e9,
+        "frac": alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": traffic_step,
+        "bytes_per_alignment": b_alg, "algorithmic_bytes_per_step": alg_step,
+        "traffic_step_bytes": traffic_step,
+        "waste_ratio": (traffic_step / alg_step) if traffic_step else None,
+        "launches_per_step": tr.get("launches_per_step"),
+        "device_ms_per_step": dev_ms,
+        "records_after_combine": m,
+    }
+    if dominant in timed:
+        launches, total_ms = timed[dominant]
+        avg_ms = total_ms / launches
+        kb = KERNEL_BYTES.get(dominant, lambda *a: 0)(n, n_words, r, m)
+        out.update({
+            "kernel": dominant, "kernel_launches_per_step": launches / steps, "kernel_avg_ms": avg_ms,
+            "kernel_bytes_per_launch": kb, "kernel_achieved": kb / (avg_ms * 1e-3) / 1e9,
+            "kernel_frac": kb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_traffic": tr.get(dominant),
+        })
+    if stats:
+        out["kernels_ms_per_step"] = {k: v[1] / breakdown_steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])}
+    return out
+
+
+def run_single(kind, batch, names, genome, dev, local_rank, steps, warmup, prefix):
+    """one workload on one GPU, no collectives: the `configs` entries"""
+    import torch
+    import intronprospector_amd as ipa
+    from intronprospector_amd import _lib as L
+    n, n_words = len(batch["tid"]), len(batch["cigar"])
+    arrays, ptrs = upload(batch, dev)
+    params = _oracle_params(kind)
+    pack = None
+    if genome is not None:
+        pack = (genome.names, [(t, m, len(q)) for (t, m), q in zip(genome.twobit(), genome.seqs)])
+        params.update(genome=pack, junction_filter=L.IPX_SJ_CANON)
+    ex = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
+    ex.reserve(0, 0, n_words // 2 + 1024)
+    table = None
+
+    def step():
+        ex.clear()
+        ex.push_device(n, n_words, ptrs, base_read_index=0)
+        m = ex.records_pending()
+        rc, t = ex.finalize_raw(L.IPX_MEM_DEVICE)
+        if rc:
+            ex._check(rc)
+        return t, m
+    for _ in range(warmup):
+        table, m = step()
+    ex.profile(True)
+    table, m = step()
+    torch.cuda.synchronize()
+    warm = ex.profile_read()
+    cand = {k: v for k, v in warm.items() if k in ("k_scan", "k_scatter", "k_reduce")}
+    dominant = max(cand.items(), key=lambda kv: kv[1][1])[0] if cand else "k_scan"
+    ex.profile_only(dominant)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        table, m = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timed = ex.profile_read()
+    ex.profile(True)
+    for _ in range(2):
+        table, m = step()
+    torch.cuda.synchronize()
+    stats = ex.profile_read()
+    ex.profile(False)
+    r, nj = int(table.n_records), int(table.n_junctions)
+    ex.close()
+    del arrays
+    ms = elapsed / steps * 1e3
+    roof = roofline_block(kind, n, n_words, r, m, ms, dominant, timed, stats, 2, steps)
+    out = {"workload": kind, "alignments": n, "cigar_words": n_words, "records": r, "junctions": nj, "steps": steps,
+           "ms_per_step": ms, "value": n * steps / elapsed, "unit": "alignments/s",
+           "frac": roof["frac"], "achieved": roof["achieved"], "kernel": roof.get("kernel"),
+           "kernel_frac": roof.get("kernel_frac"), "kernel_avg_ms": roof.get("kernel_avg_ms"),
+           "records_after_combine": m, "kernels_ms_per_step": roof.get("kernels_ms_per_step")}
+    if prefix:
+        out["parity_prefix"] = parity_prefix(kind, batch, names, pack, genome, prefix, local_rank)
+    return out
 
 
 def main():
@@ -83,9 +351,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="S", choices=["S", "L", "G"])
-    ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10M for S, 200k for L)")
+    ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10 M for S and G, 2 M for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` sub-records (L at 2 M, G at 10 M) of the default single-GPU S run")
     ap.add_argument("--shuffle", action="store_true",
                     help="alignments in random order instead of coordinate order (the reference's whole-file mode "
                          "accepts unsorted input): what the step costs without any locality")
@@ -103,7 +373,25 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    import torch
+
+    import torch            # before the package: libipx.so must bind to the HIP runtime torch brings along
+    from intronprospector_amd import synth
+    kind = args.workload
+    reads = args.reads or DEFAULT_READS[kind]
+    seed = (synth.SEED_L if kind == "L" else synth.SEED_S) if world == 1 else synth.SEED_M0 + rank
+    t_gen = time.perf_counter()
+    batch, names, genome = make_workload(kind, reads, seed)
+    if args.shuffle:
+        batch = synth.permute_batch(batch, np.random.default_rng(seed + 7).permutation(len(batch["tid"])))
+    t_gen = time.perf_counter() - t_gen
+    n = len(batch["tid"])
+    n_words = len(batch["cigar"])
+
+    # CPU baseline first: its worker processes start before this process touches the GPU
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(batch, names, kind, args.cpu_sample or n)
+
     import torch.distributed as dist
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -119,31 +407,15 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import intronprospector_amd as ipa
-    from intronprospector_amd import synth
     from intronprospector_amd import _lib as L
 
-    kind = args.workload
-    reads = args.reads or (200_000 if kind == "L" else 10_000_000)
-    seed = (synth.SEED_L if kind == "L" else synth.SEED_S) if world == 1 else synth.SEED_M0 + rank
-    t_gen = time.perf_counter()
-    batch, names, genome = make_workload(kind, reads, seed)
-    if args.shuffle:
-        import numpy as np
-        batch = synth.permute_batch(batch, np.random.default_rng(seed + 7).permutation(len(batch["tid"])))
-    t_gen = time.perf_counter() - t_gen
-    n = len(batch["tid"])
-    n_words = len(batch["cigar"])
-
-    keys = ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")
-    dev_arrays = [torch.from_numpy(batch[k]).to(dev) for k in keys]
-    ptrs = [t.data_ptr() for t in dev_arrays]
-    torch.cuda.synchronize()
-
-    params = {"max_anchor_indel_size": 36} if kind == "L" else {}
+    dev_arrays, ptrs = upload(batch, dev)
+    params = _oracle_params(kind)
+    genome_pack = None
     if genome is not None:      # device 2-bit genome; filter as the command line defaults to with a genome
-        params["genome"] = (genome.names, [(t, m, len(q)) for (t, m), q in zip(genome.twobit(), genome.seqs)])
+        genome_pack = (genome.names, [(t, m, len(q)) for (t, m), q in zip(genome.twobit(), genome.seqs)])
+        params["genome"] = genome_pack
         params["junction_filter"] = L.IPX_SJ_CANON
-        genome = None
     ex = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
     ex.reserve(0, 0, n_words // 2 + 1024)
 
@@ -159,10 +431,12 @@ def main():
 
     n_records = [0]
     n_merged = [0]
+    n_items = [0]
 
     def step():
         ex.clear()
         ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
+        n_items[0] = ex.records_pending()
         if exchanger is not None:
             # junction records -> key-range owners over RCCL (all_to_all), then the local finalize
             table, ijunc = exchanger.run(ex, n)
@@ -183,7 +457,7 @@ def main():
 
     # A probe step with event pairs around every launch tells which kernel class dominates.  The timed region
     # then brackets the launches of that class alone (an event before and after each): pairs around all
-    # ~70 launches of a step cost a 10 M-alignment step about 10 % of its time.
+    # launches of a step cost a 10 M-alignment step about 10 % of its time.
     for _ in range(args.warmup):
         table = step()
     ex.profile(True)              # one more untimed step, all launches bracketed (the first steps also allocate)
@@ -218,44 +492,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if exchanger is not None:
-        tot = torch.tensor([n_merged[0]], dtype=torch.int64, device=comm_dev)
+        tot = torch.tensor([n_merged[0], int(n_records[0])], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(tot)
-        n_merged[0] = int(tot.item())
+        n_merged[0] = int(tot[0].item())
+        n_records[0] = int(tot[1].item()) // world       # records per GPU (after the exchange a rank holds a key range)
     n_junctions = n_merged[0] if multi else int(table.n_junctions)
     r = int(n_records[0])
+    ex.close()
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed
         c = n_words / n
         j = r / n
-        b_alg = 20 + 4 * c + 64 * j                      # SURVEY.md 8(d), bytes per alignment
-        dev_ms = sum(v[1] for v in stats.values()) / breakdown_steps
-        dom = (dominant, timed[dominant]) if dominant in timed else None
-        roofline = None
-        if dom:
-            name, (launches, total_ms) = dom
-            avg_ms = total_ms / launches
-            kb = KERNEL_BYTES.get(name, lambda n_, w_, r_: 0)(n, n_words, r)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(kind, {}).get(name)
-                except Exception:
-                    traffic = None
-            roofline = {
-                "bound": "hbm", "kernel": name, "launches_per_step": launches / args.steps,
-                "avg_ms": avg_ms, "algorithmic_bytes_per_launch": kb,
-                "achieved": kb / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                # whole path: SURVEY 8(d) algorithmic bytes over ALL device time of a step
-                "pipeline": {"bytes_per_alignment": b_alg, "device_ms_per_step": dev_ms,
-                             "achieved": b_alg * n / (dev_ms * 1e-3) / 1e9 if dev_ms else None,
-                             "frac": b_alg * n / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dev_ms else None},
-                # from breakdown_steps extra steps after the timed region (every launch bracketed there)
-                "kernels_ms_per_step": {k: v[1] / breakdown_steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
-            }
+        roofline = roofline_block(kind, n, n_words, r, n_items[0], ms_per_step, dominant, timed, stats, breakdown_steps,
+                                  args.steps)
         out = {
             "metric": "alignments/sec junction extraction", "value": value, "unit": "alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -267,14 +519,37 @@ def main():
                                     (", device 2-bit genome, --sj-filter=canon" if kind == "G" else ""),
                                     c, j, n_junctions),
                        "alignments_per_gpu": n, "cigar_words": n_words, "records": r, "junctions": n_junctions,
-                       "order": "shuffled" if args.shuffle else "coordinate-sorted", "seed": seed, "generate_s": t_gen},
+                       "input": "SoA batch resident in HBM before the timed region (decode and H2D excluded)",
+                       "order": "shuffled" if args.shuffle else "coordinate-sorted", "seed": seed, "generate_s": t_gen,
+                       "multi": (args.multi if multi else None)},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or n
-            out["cpu_baseline"] = cpu_baseline(batch, names, kind, sample)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if world == 1 and not multi and not args.shuffle:
+            try:        # the benchmark's own batch, a prefix of it, device against oracle
+                out["config"]["parity_prefix"] = parity_prefix(kind, batch, names, genome_pack, genome,
+                                                               20_000 if kind == "L" else 200_000, local_rank)
+            except Exception as e:
+                out["config"]["parity_prefix"] = {"error": repr(e)[:300]}
+    # BASELINE.json's other single-GPU configurations, in the same run
+    if rank == 0 and world == 1 and not multi and kind == "S" and not args.no_configs and not args.shuffle and not args.reads:
+        del dev_arrays, batch
+        configs = {}
+        for k2, steps2, prefix in (("G", 10, 200_000), ("L", 5, 20_000)):
+            t1 = time.perf_counter()
+            try:
+                b2, names2, g2 = make_workload(k2, DEFAULT_READS[k2], synth.SEED_L if k2 == "L" else synth.SEED_S)
+                gen_s = time.perf_counter() - t1
+                rec = run_single(k2, b2, names2, g2, dev, local_rank, steps2, 2, prefix)
+                rec["generate_s"] = gen_s
+                configs[k2] = rec
+                del b2, g2
+            except Exception as e:                   # the headline line must still come out
+                configs[k2] = {"error": repr(e)[:300]}
+        out["configs"] = configs
+    if rank == 0:
         print(json.dumps(out))
-    ex.close()
     if multi:
         dist.destroy_process_group()
 

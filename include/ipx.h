@@ -167,6 +167,11 @@ typedef struct ipx_error {
     int32_t  retlen;      /* IPX_DATA_GENOME_SHORT: bytes the fetch returned */
     char     op;          /* IPX_DATA_CIGAR: the operation character */
     char     detail[235]; /* human-readable text (HIP error string, ...) */
+    uint64_t order;       /* IPX_EDATA: where the error lies in input order (alignment, then record inside
+                             the alignment, then kind); smaller = earlier, comparable between the handles
+                             of one run: a multi-GPU caller raises the error with the smallest order
+                             (junctions_extractor.cc throws at the first one its loop meets).
+                             ~0 for every other status */
 } ipx_error;
 
 typedef struct ipx_handle ipx_handle;

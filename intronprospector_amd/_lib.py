@@ -63,7 +63,7 @@ class Error(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("kind", C.c_int32), ("read_index", C.c_uint64), ("target", C.c_uint32),
         ("start", C.c_uint32), ("end", C.c_uint32), ("retlen", C.c_int32), ("op", C.c_char),
-        ("detail", C.c_char * 235),
+        ("detail", C.c_char * 235), ("order", C.c_uint64),
     ]
 
 

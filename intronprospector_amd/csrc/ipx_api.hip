@@ -146,6 +146,7 @@ namespace {
 int fail(ipx_handle *h, int status, const char *fmt, const char *a = "", long b = 0) {
     if (h) {
         h->err.status = status;
+        h->err.order = ~0ull;
         snprintf(h->err.detail, sizeof h->err.detail, fmt, a, b);
     }
     return status;
@@ -154,6 +155,7 @@ int fail(ipx_handle *h, int status, const char *fmt, const char *a = "", long b 
 int fail_hip(ipx_handle *h, hipError_t e, const char *what, int line) {
     if (h) {
         h->err.status = (e == hipErrorOutOfMemory) ? IPX_ENOMEM : IPX_EDEVICE;
+        h->err.order = ~0ull;
         snprintf(h->err.detail, sizeof h->err.detail, "%s: %s (ipx_api.hip:%d)", what, hipGetErrorString(e), line);
         return h->err.status;
     }
@@ -337,6 +339,7 @@ int grow_records(ipx_handle *h, uint64_t cap) {
 void fill_data_error(ipx_handle *h, unsigned long long w) {
     ipx_error &e = h->err;
     e.status = IPX_EDATA;
+    e.order = w;
     e.read_index = IPX_ORD_READ(w);
     e.target = 0xffffffffu;
     const uint32_t kind = (uint32_t)(w >> 8) & 3u, detail = (uint32_t)w & 0xffu;

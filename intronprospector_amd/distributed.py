@@ -23,21 +23,82 @@ import torch
 import torch.distributed as dist
 
 BIG = (1 << 62)
+ERR_NONE = (1 << 64) - 1        # ipx_error.order of "no error"
 
 
-def _all_gather_var(t, group=None):
-    """all_gather of 1-D/2-D tensors whose first dimension differs per rank."""
+class ShardError:
+    """What one rank found wrong with its share of the input: `order` places it in the run's input order
+    (ipx_error.order; 0 for a failure that is not about the data, so that it wins), `blob` is the rank's
+    ipx_error as bytes, `status` its ipx status."""
+
+    def __init__(self, order=ERR_NONE, blob=b"", status=0):
+        self.order, self.blob, self.status = int(order), bytes(blob), int(status)
+
+    @classmethod
+    def from_ipx(cls, exc):
+        import ctypes as C
+        blob = bytes((C.c_char * C.sizeof(exc.err)).from_buffer_copy(exc.err)) if getattr(exc, "err", None) is not None else b""
+        from . import _lib as L
+        return cls(exc.order if exc.status == L.IPX_EDATA else 0, blob, exc.status)
+
+    def raise_(self):
+        from . import _lib as L
+        from .extractor import IpxError
+        e = L.Error.from_buffer_copy(self.blob.ljust(__import__("ctypes").sizeof(L.Error), b"\0"))
+        raise IpxError(self.status or e.status or L.IPX_EDEVICE, e)
+
+
+def _all_gather_var(t, group=None, local_error=None):
+    """all_gather of 1-D/2-D tensors whose first dimension differs per rank.
+
+    local_error (a ShardError or None on EVERY rank that passes the argument): the ranks' sizes travel
+    with the ranks' error orders; if some rank has an error, every rank raises the one that comes first
+    in input order -- the reference throws at the first bad alignment its loop meets
+    (junctions_extractor.cc:73-74,312-313) -- before anybody enters the data collective, so nobody is
+    left waiting in it."""
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    head = [t.shape[0]]
+    if local_error is not None:
+        head += [local_error.order >> 32, local_error.order & 0xffffffff, local_error.status]
+    n = torch.tensor(head, dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
-    sizes = torch.cat(sizes).cpu().tolist()          # one read-back
+    rows = torch.stack(sizes).cpu().tolist()         # one read-back
+    if local_error is not None:
+        _raise_earliest([(r[1] << 32) | r[2] for r in rows], local_error, group, t.device)
+    sizes = [r[0] for r in rows]
     m = max(max(sizes), 1)
     pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def _raise_earliest(orders, local_error, group, device):
+    """orders: every rank's error order (ERR_NONE = fine).  Returns if all are fine; otherwise the rank
+    with the smallest order (ties: the lowest rank) broadcasts its ipx_error and EVERY rank raises it."""
+    import ctypes as C
+    from . import _lib as L
+    best = min(range(len(orders)), key=lambda r: (orders[r], r))
+    if orders[best] == ERR_NONE:
+        return
+    size = C.sizeof(L.Error) + 8
+    rank = dist.get_rank(group)
+    buf = torch.zeros(size, dtype=torch.uint8, device=device)
+    if rank == best:
+        raw = local_error.status.to_bytes(8, "little") + local_error.blob.ljust(C.sizeof(L.Error), b"\0")
+        buf = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    src = dist.get_global_rank(group, best) if group is not None else best
+    dist.broadcast(buf, src=src, group=group)
+    raw = bytes(buf.cpu().numpy().tobytes())
+    ShardError(orders[best], raw[8:], int.from_bytes(raw[:8], "little")).raise_()
+
+
+def agree_on_error(local_error, group=None, device="cpu"):
+    """Stand-alone form of the agreement (one tiny all_gather): returns when no rank has an error, else every
+    rank raises the globally earliest one."""
+    _all_gather_var(torch.zeros(0, dtype=torch.int64, device=device), group, local_error or ShardError())
 
 
 def _keys(tab):
@@ -66,17 +127,18 @@ def _find_rows(union, keys):
     return idx
 
 
-def merge_shard_tables(fc, al, shard_begin_order, group=None):
+def merge_shard_tables(fc, al, shard_begin_order, group=None, local_error=None):
     """fc / al: the shard's from-creator and all-records tables as dicts of torch
     tensors (target,intron_start,intron_end,anchor_start,anchor_end,strand,motif,
     counts[n,3],creator_order,hist_begin[n+1],hist_value,hist_count).
     shard_begin_order: smallest creator_order any record of this shard can have
     (first global read index << 20).  Returns the merged table (same on all ranks),
-    rows in key order, ijunc = rank of creation."""
+    rows in key order, ijunc = rank of creation.
+    local_error: this shard's ShardError (or None on every rank): all ranks raise the earliest."""
     dev = al["target"].device
     k_al, k_fc = _keys(al), _keys(fc)
-    # 1. union of keys
-    parts = _all_gather_var(k_al, group)
+    # 1. union of keys (the shards' errors, if any, travel with the sizes: see _all_gather_var)
+    parts = _all_gather_var(k_al, group, local_error)
     allk = torch.cat(parts, dim=0)
     if allk.shape[0] == 0:
         empty = {k: v[:0] for k, v in al.items() if k not in ("hist_begin",)}
@@ -181,6 +243,15 @@ def table_to_torch(ex, t, device):
     return out
 
 
+def empty_table(device):
+    z = lambda dt: torch.zeros(0, dtype=dt, device=device)
+    t = {k: z(torch.int64) for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "motif",
+                                     "creator_order", "hist_value", "hist_count")}
+    t["counts"] = torch.zeros((0, 3), dtype=torch.int64, device=device)
+    t["hist_begin"] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
 class RecordExchanger:
     """Multi-GPU by key range: every rank scans its own alignments, the junction RECORDS are
     exchanged once (all_to_all over RCCL) so that each rank owns a contiguous key range, and
@@ -245,14 +316,23 @@ class RecordExchanger:
         splitters = self._splitters
         t0 = self._lap("splitters", t0)
         # 2. partition my records by key range
+        from .extractor import IpxError
+        failed = None                    # a ShardError once something went wrong on THIS rank
         send = torch.empty(max(n_local, 1) * 32, dtype=torch.uint8, device=self.device)
-        counts = ex.records_partition(splitters, send.data_ptr())
+        try:
+            counts = ex.records_partition(splitters, send.data_ptr())
+        except IpxError as exc:
+            failed = ShardError.from_ipx(exc)
+            counts = np.zeros(world, np.uint64)
         t0 = self._lap("partition", t0)
-        # 3. who sends how much to whom, then the exchange itself
-        c = torch.from_numpy(counts.astype(np.int64)).to(self.comm_device)
+        # 3. who sends how much to whom (and whether everybody got this far), then the exchange itself
+        c = torch.from_numpy(np.concatenate([counts.astype(np.int64), [1 if failed else 0]])).to(self.comm_device)
         cm = [torch.empty_like(c) for _ in range(world)]
         dist.all_gather(cm, c, group=self.group)
         cmat = torch.stack(cm).cpu()                                   # one read-back, not one per rank
+        if int(cmat[:, world].sum()):                                  # some rank failed: all leave together
+            agree_on_error(failed, self.group, self.comm_device)
+        cmat = cmat[:, :world]
         recv_counts = cmat[:, rank].tolist()
         n_recv = sum(recv_counts)
         per_rank = cmat.sum(dim=0).to(torch.float64)                   # records each rank receives
@@ -267,15 +347,20 @@ class RecordExchanger:
         if recv.device.type == "cuda":
             torch.cuda.synchronize(recv.device)
         t0 = self._lap("all_to_all", t0)
-        # 4. the key range is now local: ordinary finalize
-        ex.records_adopt(n_recv, recv.data_ptr(), n_alignments_local)
-        t0 = self._lap("adopt", t0)
-        rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
-        if rc:
-            ex._check(rc)
+        # 4. the key range is now local: ordinary finalize.  A data error (IPX_EDATA: an alignment the reference
+        #    throws at) or a failure is not raised here but agreed on in step 5's first collective
+        table = None
+        try:
+            ex.records_adopt(n_recv, recv.data_ptr(), n_alignments_local)
+            t0 = self._lap("adopt", t0)
+            rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
+            if rc:
+                ex._check(rc)
+        except IpxError as exc:
+            failed = ShardError.from_ipx(exc)
         t0 = self._lap("finalize", t0)
         # 5. sjN numbering is global: rank of the creation order over all ranks' junctions
-        n = int(table.n_junctions)
+        n = int(table.n_junctions) if failed is None else 0
         co = torch.empty(n, dtype=torch.int64, device=self.device)
         if n:
             ex._check(ex.lib.ipx_copy(ex.h, co.data_ptr(), table.creator_order, n * 8))
@@ -287,7 +372,7 @@ class RecordExchanger:
         co_sorted = torch.empty_like(co)
         co_sorted[lij.to(torch.int64)] = co
         co_c = self._to_comm(co)
-        parts = _all_gather_var(self._to_comm(co_sorted), self.group)
+        parts = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError())
         ijunc = torch.zeros(n, dtype=torch.int64, device=co_c.device)
         for part in parts:
             if part.numel():
@@ -306,12 +391,19 @@ class TableMerger:
     def merge(self, ex, shard_first_read_index):
         from . import _lib as L
         import ctypes as C
+        from .extractor import IpxError
         fc, al = L.Table(), L.Table()
-        rc = ex.lib.ipx_finalize_shard(ex.h, L.IPX_MEM_DEVICE, C.byref(fc), C.byref(al))
-        if rc:
-            ex._check(rc)
-        t_fc = table_to_torch(ex, fc, self.device)
-        same = (fc.target == al.target)
-        t_al = t_fc if same else table_to_torch(ex, al, self.device)
-        merged = merge_shard_tables(t_fc, t_al, int(shard_first_read_index) << 20, self.group)
+        failed = None
+        try:
+            rc = ex.lib.ipx_finalize_shard(ex.h, L.IPX_MEM_DEVICE, C.byref(fc), C.byref(al))
+            if rc:
+                ex._check(rc)
+            t_fc = table_to_torch(ex, fc, self.device)
+            same = (fc.target == al.target)
+            t_al = t_fc if same else table_to_torch(ex, al, self.device)
+        except IpxError as exc:
+            # every rank raises the earliest error of the run in merge_shard_tables' first collective
+            failed = ShardError.from_ipx(exc)
+            t_fc = t_al = empty_table(self.device)
+        merged = merge_shard_tables(t_fc, t_al, int(shard_first_read_index) << 20, self.group, failed or ShardError())
         return merged, fc

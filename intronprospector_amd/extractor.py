@@ -20,6 +20,8 @@ class IpxError(RuntimeError):
         self.read_index = err.read_index
         self.target = err.target
         self.detail = err.detail.decode(errors="replace")
+        self.order = int(getattr(err, "order", (1 << 64) - 1))
+        self.err = err               # the ipx_error itself (a multi-GPU caller hands it to its peers)
         super().__init__(self.detail or ("ipx status %d" % status))
 
 
@@ -64,11 +66,14 @@ class JunctionsExtractor:
             self.set_genome(*genome)
 
     # -- configuration -----------------------------------------------------
+    def last_error(self):
+        e = L.Error()
+        self.lib.ipx_last_error(self.h, C.byref(e))
+        return e
+
     def _check(self, rc):
         if rc:
-            e = L.Error()
-            self.lib.ipx_last_error(self.h, C.byref(e))
-            raise IpxError(rc, e)
+            raise IpxError(rc, self.last_error())
 
     def set_targets(self, names, lengths=None):
         arr = (C.c_char_p * len(names))(*[n.encode() if isinstance(n, str) else n for n in names])

@@ -112,3 +112,78 @@ def test_shard_merge_equals_single_run(world, genome, oracle_lib):
     ok, msg, n = run_workers(_worker, world, (_free_port(), genome), timeout=300)
     assert ok, "merged table differs from the single run in: %s" % msg
     assert n > 100
+
+
+def _error_worker(rank, world, port, case, q):
+    """Every rank must raise the SAME error -- the earliest in input order -- and nobody may hang."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        from intronprospector_amd import _lib as L
+        from intronprospector_amd.distributed import ShardError, merge_shard_tables, empty_table, agree_on_error
+        from intronprospector_amd.extractor import IpxError
+
+        def err(status, kind, read_index, ordinal, errk, detail, text):
+            e = L.Error()
+            e.status, e.kind, e.read_index = status, kind, read_index
+            e.detail = text.encode()
+            e.order = (read_index << 30) | (ordinal << 10) | (errk << 8) | detail
+            return ShardError(e.order if status == L.IPX_EDATA else 0,
+                              bytes((C.c_char * C.sizeof(e)).from_buffer_copy(e)), status)
+        mine = None
+        if case == "two":            # a 'P' op on the last rank's shard, a FUNMAP spliced read on rank 0's
+            if rank == world - 1:
+                mine = err(L.IPX_EDATA, L.IPX_DATA_CIGAR, 500 + rank, 0, 0, ord("P"), "Unknown cigar operation 'P'")
+            if rank == 0:
+                mine = err(L.IPX_EDATA, L.IPX_DATA_CATEGORY, 7, 1, 2, 0, "should never look at FQCAIL, FUNMAP, FDUP reads")
+        elif case == "one":          # only the last rank has something to report
+            if rank == world - 1:
+                mine = err(L.IPX_EDATA, L.IPX_DATA_CIGAR, 500 + rank, 0, 0, ord("B"), "Unknown cigar operation 'B'")
+        elif case == "hard":         # a device failure on rank 1 beats any data error
+            if rank == 1:
+                mine = err(L.IPX_EDEVICE, 0, 0, 0, 0, 0, "hipErrorLaunchFailure")
+            if rank == 0:
+                mine = err(L.IPX_EDATA, L.IPX_DATA_CIGAR, 3, 0, 0, ord("P"), "Unknown cigar operation 'P'")
+        got = None
+        try:
+            if case == "none":
+                agree_on_error(None)
+            else:
+                merge_shard_tables(empty_table("cpu"), empty_table("cpu"), rank << 32, local_error=mine or ShardError())
+        except IpxError as e:
+            got = (str(e), int(e.read_index), int(e.status), int(e.kind))
+        everybody = [None] * world
+        dist.all_gather_object(everybody, got)
+        if rank == 0:
+            q.put(everybody)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "two"), (3, "two"), (2, "one"), (2, "hard"), (2, "none")])
+def test_shard_errors_all_ranks_raise_the_earliest(world, case):
+    """junctions_extractor.cc:73-74,312-313: the reference throws at the FIRST bad alignment of the input;
+    sharded, every rank must leave with that one (a rank that raised alone left its peers in
+    the next collective for good).  The bounded timeout of run_workers is the hang detector."""
+    from tests.mp_util import run_workers
+    from intronprospector_amd import _lib as L
+    got = run_workers(_error_worker, world, (_free_port(), case), timeout=120)
+    assert len(got) == world and all(g == got[0] for g in got), got
+    if case == "two":
+        assert got[0] == ("should never look at FQCAIL, FUNMAP, FDUP reads", 7, L.IPX_EDATA, L.IPX_DATA_CATEGORY)
+    elif case == "one":
+        assert got[0] == ("Unknown cigar operation 'B'", 500 + world - 1, L.IPX_EDATA, L.IPX_DATA_CIGAR)
+    elif case == "hard":
+        assert got[0][0] == "hipErrorLaunchFailure" and got[0][2] == L.IPX_EDEVICE
+    else:
+        assert got[0] is None
+
+
+def test_shard_merge_world_8(oracle_lib):
+    """the merge protocol with as many ranks as an MI355X node has GPUs"""
+    from tests.mp_util import run_workers
+    ok, msg, n = run_workers(_worker, 8, (_free_port(), False), timeout=600)
+    assert ok, "merged table differs from the single run in: %s" % msg
+    assert n > 100

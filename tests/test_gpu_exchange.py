@@ -117,3 +117,58 @@ def test_record_exchange_keeps_its_splitters_while_balanced(oracle_lib):
     # drawn once for the first batch, kept for the second and (still) for the skewed third, drawn again for the fourth
     assert drawn == [1, 1, 1, 2], drawn
     assert min(nper_last) > 0, nper_last
+
+
+def _error_worker(rank, world, port, path, q):
+    """A 'P' operation in rank 1's shard and a spliced FUNMAP read in rank 0's: both paths, both ranks,
+    one error -- the one the reference's loop meets first."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import intronprospector_amd as ipa
+        from intronprospector_amd import synth
+        from intronprospector_amd.distributed import RecordExchanger, TableMerger
+        from intronprospector_amd.extractor import IpxError
+        from tests.oracle_binding import Oracle, OracleError
+        batch, names, _ = synth.short_reads(40_000, seed=52, n_targets=4, target_len=2_800_000, n_sites=700)
+        n = len(batch["tid"])
+        cuts = np.linspace(0, n, world + 1).astype(int)
+        plain = np.nonzero((batch["n_cigar"] == 3) & (batch["flag"] == 0) & (batch["nh"] == 1))[0]
+        i0 = int(plain[(plain > 100) & (plain < cuts[1] - 100)][5])          # rank 0's shard
+        i1 = int(plain[plain > cuts[1] + 100][5])                            # rank 1's shard
+        batch["flag"][i0] |= 0x4                                             # FUNMAP with a spliced CIGAR: :73-74
+        w = int(batch["cigar_off"][i1])
+        batch["cigar"][w] = (batch["cigar"][w] & ~np.uint32(0xf)) | np.uint32(6)   # 'P': :312-313
+        expect = None
+        try:
+            ora = Oracle(targets=names)
+            ora.process(batch)
+        except OracleError as e:
+            expect = (e.msg, int(e.index))
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        ex = ipa.JunctionsExtractor(targets=names)
+        ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
+        got = None
+        try:
+            if path == "exchange":
+                RecordExchanger(torch.device("cuda", 0), comm_device=torch.device("cpu")).run(ex, hi - lo)
+            else:
+                TableMerger(torch.device("cpu")).merge(ex, lo)
+        except IpxError as e:
+            got = (str(e), int(e.read_index))
+        ex.close()
+        everybody = [None] * world
+        dist.all_gather_object(everybody, got)
+        if rank == 0:
+            q.put((everybody, expect, i0, i1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("path", ["exchange", "tables"])
+def test_two_ranks_raise_the_earliest_error_of_the_run(path, oracle_lib):
+    from tests.mp_util import run_workers
+    everybody, expect, i0, i1 = run_workers(_error_worker, 2, (_free_port(), path), timeout=240)
+    assert expect is not None and expect[1] == i0 < i1, (expect, i0, i1)
+    assert everybody[0] == everybody[1] == expect, (everybody, expect)

@@ -283,6 +283,32 @@ typedef struct ipx_record {
 #define IPX_RECORD_STRAND(order) ((char)(((order) >> 2) & 0xff))
 int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64_t *n_records);
 
+/* --- several GPUs of one node behind one object (SURVEY.md 8b "device list", 8e) ---------------------
+ * An ipx_group stands where ONE JunctionsExtractor stands (junctions_extractor.hh:73-256) and spreads its
+ * alignments over n_devices GPUs of the calling process: every pushed batch is cut into n_devices contiguous
+ * ranges of the read index (base_read_index keeps the order global), each device scans its range; finalize
+ * exchanges the junction records by key range -- one grouped ncclSend/ncclRecv all-to-all over RCCL/xGMI,
+ * librccl loaded at run time -- so that every junction's records meet on one device, reduces there with the
+ * single-GPU semantics, and returns ONE table in host memory: rows in key order, ijunc the creation rank over
+ * the whole run, the earliest data error of all devices reported as ipx_finalize would.  A device ordinal
+ * listed twice makes two members share that GPU (rehearsal on a one-GPU box): the exchange then moves the
+ * parts with peer copies instead of RCCL.  devices == NULL means 0 .. n_devices-1. */
+typedef struct ipx_group ipx_group;
+int ipx_group_create(const ipx_params *params, uint32_t n_devices, const int32_t *devices, ipx_group **out);
+int ipx_group_destroy(ipx_group *g);
+int ipx_group_set_targets(ipx_group *g, uint32_t n, const char *const *names, const int64_t *lengths);
+int ipx_group_set_genome_2bit(ipx_group *g, uint32_t n_seqs, const char *const *names, const int64_t *lengths,
+                              const uint8_t *const *twobit, const uint8_t *const *mask);
+int ipx_group_set_option(ipx_group *g, int32_t option, int64_t value);
+/* batch in host memory (IPX_MEM_HOST), CIGAR words laid out in alignment order */
+int ipx_group_push_batch(ipx_group *g, const ipx_batch *batch);
+/* table in host memory, owned by the group, valid until the next finalize / clear / destroy */
+int ipx_group_finalize(ipx_group *g, ipx_table *out);
+int ipx_group_clear(ipx_group *g);
+int ipx_group_last_error(const ipx_group *g, ipx_error *out);
+/* 1 if the group's exchange runs over RCCL, 0 if over peer copies (members sharing a device) */
+int ipx_group_uses_rccl(const ipx_group *g);
+
 /* copy between any two of {host, device} on the handle's stream, then wait */
 int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes);
 

@@ -8,4 +8,5 @@ from . import _lib
 
 _lib.load()
 
-from .extractor import JunctionsExtractor, IpxError, expand_histogram, offsets_per_junction  # noqa: E402,F401
+from .extractor import (JunctionsExtractor, JunctionsExtractorGroup, IpxError, expand_histogram,  # noqa: E402,F401
+                        offsets_per_junction)

@@ -25,6 +25,9 @@ SYMBOLS = [
     "ipx_finalize_shard", "ipx_copy", "ipx_records_pending", "ipx_records_sample",
     "ipx_records_partition", "ipx_records_adopt", "ipx_records_export", "ipx_last_timing", "ipx_profile",
     "ipx_profile_only", "ipx_profile_read", "ipx_set_option",
+    "ipx_group_create", "ipx_group_destroy", "ipx_group_set_targets", "ipx_group_set_genome_2bit",
+    "ipx_group_set_option", "ipx_group_push_batch", "ipx_group_finalize", "ipx_group_clear",
+    "ipx_group_last_error", "ipx_group_uses_rccl",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -108,6 +111,17 @@ def load():
     lib.ipx_profile.argtypes = [vp, C.c_int]
     lib.ipx_profile_only.argtypes = [vp, C.c_char_p]
     lib.ipx_profile_read.argtypes = [vp, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ipx_group_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(vp)]
+    lib.ipx_group_destroy.argtypes = [vp]
+    lib.ipx_group_set_targets.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]
+    lib.ipx_group_set_genome_2bit.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                              C.POINTER(vp), C.POINTER(vp)]
+    lib.ipx_group_set_option.argtypes = [vp, C.c_int32, C.c_int64]
+    lib.ipx_group_push_batch.argtypes = [vp, C.POINTER(Batch)]
+    lib.ipx_group_finalize.argtypes = [vp, C.POINTER(Table)]
+    lib.ipx_group_clear.argtypes = [vp]
+    lib.ipx_group_last_error.argtypes = [vp, C.POINTER(Error)]
+    lib.ipx_group_uses_rccl.argtypes = [vp]
     for name in SYMBOLS:
         getattr(lib, name)
     _lib = lib

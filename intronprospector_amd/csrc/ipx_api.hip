@@ -367,6 +367,16 @@ void fill_data_error(ipx_handle *h, unsigned long long w) {
     }
 }
 
+GenomeDev genome_dev(const ipx_handle *h) {
+    GenomeDev g{};
+    if (h->have_genome) {
+        g.twobit = h->d_twobit.as<uint32_t>(); g.mask = h->d_mask.as<uint32_t>();
+        g.seq_len = h->d_seq_len.as<int64_t>(); g.seq_word2 = h->d_seq_word2.as<uint64_t>();
+        g.seq_wordm = h->d_seq_wordm.as<uint64_t>(); g.seq_of_rank = h->d_seq_of_rank.as<int32_t>();
+    }
+    return g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -462,6 +472,8 @@ int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names
                         const uint8_t *const *twobit, const uint8_t *const *mask) {
     if (!h) return IPX_EINVAL;
     if (n_seqs && (!names || !lengths || !twobit || !mask)) return IPX_EINVAL;
+    // pending records were combined (or not) according to the genome that was set when they were pushed
+    if (h->n_records) return fail(h, IPX_EINVAL, "ipx_set_genome_2bit with records pending%s%ld", "", 0);
     (void)hipSetDevice(h->params.device);
     h->gnames.clear();
     h->glen.clear();
@@ -562,13 +574,17 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     sp.key = h->key;
     if (h->n_records == 0) h->first_window = h->first_hint;
     sp.first = h->first_window;
-    // Combining a tile's equal-key records is exact when every record of a junction is counted, i.e. when none
-    // can fail the junction filter: no genome, or a filter other than "canon" (splice_juncs.cc:52-61).  With an
-    // active filter the records before a junction's creator are dropped one by one (ipx_reduce.hip), which a
-    // merged record could straddle.  IPX_COMBINE=0 in the environment switches it off (tests compare both).
+    // Combining a tile's equal-key records is exact when every record of the group is counted.  Without a
+    // genome, or with a filter other than "canon" (splice_juncs.cc:52-61), every record is.  With an active
+    // filter the records before a junction's creator are dropped one by one (ipx_reduce.hip), and a merged
+    // record must not straddle the creator: only records that pass the filter themselves are merged (the
+    // creator is the first of those, so a group of them lies wholly at or after it), the others stay single.
+    // IPX_COMBINE=0 in the environment switches it off (tests compare both).
     static const bool combine_env = [] { const char *e = getenv("IPX_COMBINE"); return !(e && e[0] == '0'); }();
     const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
-    sp.combine = (h->opt_combine && combine_env && !filter_active) ? 1u : 0u;
+    sp.combine = (h->opt_combine && combine_env) ? (filter_active ? 2u : 1u) : 0u;
+    sp.skip_missing = h->params.skip_missing_targets;
+    if (filter_active) sp.genome = genome_dev(h);
 
     ProfScope prof_scope(&h->prof);
     // state to return to if a scan has to be repeated
@@ -782,12 +798,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             outa2.base = out_arena.as<char>();
             layout(tmp2, outa2);
         }
-        GenomeDev g{};
-        if (h->have_genome) {
-            g.twobit = h->d_twobit.as<uint32_t>(); g.mask = h->d_mask.as<uint32_t>();
-            g.seq_len = h->d_seq_len.as<int64_t>(); g.seq_word2 = h->d_seq_word2.as<uint64_t>();
-            g.seq_wordm = h->d_seq_wordm.as<uint64_t>(); g.seq_of_rank = h->d_seq_of_rank.as<int32_t>();
-        }
+        const GenomeDev g = genome_dev(h);
         HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));

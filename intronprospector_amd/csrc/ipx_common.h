@@ -68,6 +68,14 @@ struct KeyLayout {
 struct DigitSpec {
     uint32_t lo1, w1, lo2, w2;
 };
+struct GenomeDev {
+    const uint32_t *twobit;      // 16 bases per word, all sequences concatenated (word aligned per sequence)
+    const uint32_t *mask;        // 32 bases per word
+    const int64_t *seq_len;      // per genome sequence
+    const uint64_t *seq_word2;   // first twobit word of the sequence
+    const uint64_t *seq_wordm;   // first mask word of the sequence
+    const int32_t *seq_of_rank;  // per key rank: genome sequence index, -1 = missing, -2 = no genome
+};
 struct ScanParams {
     uint32_t min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length;
     int32_t strandness;
@@ -84,7 +92,12 @@ struct ScanParams {
     uint32_t n_stripes;
     // 1: k_scan_short combines equal-key records of a tile (off when the caller wants every record:
     // ipx_records_export, or when a record may fail the junction filter -- see ipx_push_batch)
+    // 2: the same under an active junction filter (genome + "canon"): a record is combined only if IT would
+    // pass the filter against its junction's motif (looked up here, per record); records that fail stay single,
+    // because the reduce drops those that precede the junction's creator one by one
     uint32_t combine;
+    int32_t skip_missing;
+    GenomeDev genome;
 };
 constexpr uint32_t IPX_STRIPES = 8;
 constexpr uint32_t IPX_STRIPE_CHUNK_BITS = 11;       // 2048 records: stripe s owns chunks s, s + 8, s + 16, ...
@@ -172,16 +185,66 @@ __device__ __forceinline__ uint32_t ipx_digit_of(const uint4 &it, const DigitSpe
 }
 #endif
 
-struct GenomeDev {
-    const uint32_t *twobit;      // 16 bases per word, all sequences concatenated (word aligned per sequence)
-    const uint32_t *mask;        // 32 bases per word
-    const int64_t *seq_len;      // per genome sequence
-    const uint64_t *seq_word2;   // first twobit word of the sequence
-    const uint64_t *seq_wordm;   // first mask word of the sequence
-    const int32_t *seq_of_rank;  // per key rank: genome sequence index, -1 = missing, -2 = no genome
-};
 
 static inline uint64_t ipx_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---- splice sites on the device genome (used per junction by k_motif, per record by the scan's combiner) ----
+__device__ __forceinline__ uint32_t ipx_base2(const GenomeDev &g, uint64_t w0, int64_t p) {
+    return (g.twobit[w0 + (uint64_t)(p >> 4)] >> ((p & 15) * 2)) & 3u;
+}
+__device__ __forceinline__ uint32_t ipx_maskbit(const GenomeDev &g, uint64_t w0, int64_t p) {
+    return (g.mask[w0 + (uint64_t)(p >> 5)] >> (p & 31)) & 1u;
+}
+
+// splice_juncs.cc:22-26 on 2-bit codes A0 C1 G2 T3: GT/AG, GC/AG, AT/AC
+__device__ __forceinline__ bool ipx_canon4(uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1) {
+    const bool gt_ag = (d0 == 2 && d1 == 3 && a0 == 0 && a1 == 2);
+    const bool gc_ag = (d0 == 2 && d1 == 1 && a0 == 0 && a1 == 2);
+    const bool at_ac = (d0 == 0 && d1 == 3 && a0 == 0 && a1 == 1);
+    return gt_ag || gc_ag || at_ac;
+}
+
+// get_splice_sites, junctions_extractor.cc:405-428, as a word: IPX_MOTIF_* bits | the four 2-bit bases;
+// error marker in bits 11..8: 0x100 = sequence missing and not skippable (:411-417, genome.cc:65-67),
+// 0x200 = a fetch ran past the end of the sequence (genome.cc:68-70)
+__device__ __forceinline__ uint32_t ipx_motif_of(const GenomeDev &g, int32_t skip_missing, uint32_t rank,
+                                                 uint32_t start, uint32_t end) {
+    const int32_t seq = g.seq_of_rank ? g.seq_of_rank[rank] : -2;
+    if (seq == -2) return 0u;                                   // no genome: splice_sites == ""
+    if (seq < 0) return skip_missing ? 0u : 0x100u;
+    const int64_t L = g.seq_len[seq];
+    const int64_t s = (int64_t)(int32_t)start, e = (int64_t)(int32_t)end;   // Genome::fetch takes int
+    // faidx clamps to the sequence; a fetch that returns fewer than 2 bases throws.
+    // acceptor [e-2,e) is fetched first (see oracle/ipxo_core.c get_splice_sites)
+    if (e - 2 < 0 || e > L || s < 0 || s + 2 > L) return 0x200u;
+    const uint64_t w2 = g.seq_word2[seq], wm = g.seq_wordm[seq];
+    const uint32_t d0 = ipx_base2(g, w2, s), d1 = ipx_base2(g, w2, s + 1);
+    const uint32_t a0 = ipx_base2(g, w2, e - 2), a1 = ipx_base2(g, w2, e - 1);
+    const uint32_t non = ipx_maskbit(g, wm, s) | ipx_maskbit(g, wm, s + 1) | ipx_maskbit(g, wm, e - 2) |
+                         ipx_maskbit(g, wm, e - 1);
+    uint32_t m = IPX_MOTIF_PRESENT | (d0 << 6) | (d1 << 4) | (a0 << 2) | a1;
+    if (non) {
+        m |= IPX_MOTIF_NONACGT;
+    } else {
+        if (ipx_canon4(d0, d1, a0, a1)) m |= IPX_MOTIF_CANON_P;
+        // reverse complement of "d0d1/a0a1" is  ~a1 ~a0 / ~d1 ~d0
+        if (ipx_canon4(3 - a1, 3 - a0, 3 - d1, 3 - d0)) m |= IPX_MOTIF_CANON_RC;
+    }
+    return m;
+}
+
+// does a record with read strand s create the junction?  (add_junction + junction_filter_check,
+// junctions_extractor.cc:488-506, splice_juncs.cc:52-61)
+__device__ __forceinline__ bool ipx_record_passes(uint32_t strand, uint32_t motif, int32_t sj_filter) {
+    if (!(motif & IPX_MOTIF_PRESENT)) return true;          // empty splice_sites pass any filter
+    if (sj_filter != IPX_SJ_CANON) return true;
+    const bool cp = motif & IPX_MOTIF_CANON_P, crc = motif & IPX_MOTIF_CANON_RC;
+    if (strand == '-') return crc;
+    if (strand == '.') return cp || crc;
+    return cp;
+}
+#endif
 
 #ifdef __HIPCC__
 // fields of a packed sort key (see the record layout above)

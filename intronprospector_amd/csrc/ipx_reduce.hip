@@ -127,22 +127,6 @@ __global__ __launch_bounds__(256) void k_write_heads(const uint4 *__restrict__ i
     }
 }
 
-// ---- genome -----------------------------------------------------------------
-__device__ __forceinline__ uint32_t base2(const GenomeDev &g, uint64_t w0, int64_t p) {
-    return (g.twobit[w0 + (uint64_t)(p >> 4)] >> ((p & 15) * 2)) & 3u;
-}
-__device__ __forceinline__ uint32_t maskbit(const GenomeDev &g, uint64_t w0, int64_t p) {
-    return (g.mask[w0 + (uint64_t)(p >> 5)] >> (p & 31)) & 1u;
-}
-
-// splice_juncs.cc:22-26 on 2-bit codes A0 C1 G2 T3: GT/AG, GC/AG, AT/AC
-__device__ __forceinline__ bool canon4(uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1) {
-    const bool gt_ag = (d0 == 2 && d1 == 3 && a0 == 0 && a1 == 2);
-    const bool gc_ag = (d0 == 2 && d1 == 1 && a0 == 0 && a1 == 2);
-    const bool at_ac = (d0 == 0 && d1 == 3 && a0 == 0 && a1 == 1);
-    return gt_ag || gc_ag || at_ac;
-}
-
 // jmotif: IPX_MOTIF_* bits | bases; error marker in bits 11..8:
 //   0x100 = sequence missing and not skippable, 0x200 = fetch ran past the end
 __global__ __launch_bounds__(256) void k_motif(uint32_t n_j, GenomeDev g, int32_t skip_missing,
@@ -152,46 +136,8 @@ __global__ __launch_bounds__(256) void k_motif(uint32_t n_j, GenomeDev g, int32_
                                                uint32_t *__restrict__ jmotif) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_j) return;
-    const int32_t seq = g.seq_of_rank ? g.seq_of_rank[jrank[j]] : -2;
-    uint32_t m = 0;
-    if (seq == -2) {
-        m = 0;                                   // no genome: splice_sites == ""
-    } else if (seq < 0) {
-        m = skip_missing ? 0u : 0x100u;          // :411-417 / genome.cc:65-67
-    } else {
-        const int64_t L = g.seq_len[seq];
-        const int64_t s = (int64_t)(int32_t)jstart[j], e = (int64_t)(int32_t)jend[j];   // Genome::fetch takes int
-        // faidx clamps to the sequence; a fetch that returns fewer than 2 bases throws (genome.cc:68-70).
-        // acceptor [e-2,e) is fetched first (see oracle/ipxo_core.c get_splice_sites)
-        if (e - 2 < 0 || e > L || s < 0 || s + 2 > L) {
-            m = 0x200u;
-        } else {
-            const uint64_t w2 = g.seq_word2[seq], wm = g.seq_wordm[seq];
-            const uint32_t d0 = base2(g, w2, s), d1 = base2(g, w2, s + 1);
-            const uint32_t a0 = base2(g, w2, e - 2), a1 = base2(g, w2, e - 1);
-            const uint32_t non = maskbit(g, wm, s) | maskbit(g, wm, s + 1) | maskbit(g, wm, e - 2) |
-                                 maskbit(g, wm, e - 1);
-            m = IPX_MOTIF_PRESENT | (d0 << 6) | (d1 << 4) | (a0 << 2) | a1;
-            if (non) {
-                m |= IPX_MOTIF_NONACGT;
-            } else {
-                if (canon4(d0, d1, a0, a1)) m |= IPX_MOTIF_CANON_P;
-                // reverse complement of "d0d1/a0a1" is  ~a1 ~a0 / ~d1 ~d0
-                if (canon4(3 - a1, 3 - a0, 3 - d1, 3 - d0)) m |= IPX_MOTIF_CANON_RC;
-            }
-        }
-    }
+    const uint32_t m = ipx_motif_of(g, skip_missing, jrank[j], jstart[j], jend[j]);
     jmotif[j] = m;
-}
-
-// does a record with read strand s create the junction?  
-__device__ __forceinline__ bool record_passes(uint32_t strand, uint32_t motif, int32_t sj_filter) {
-    if (!(motif & IPX_MOTIF_PRESENT)) return true;          // empty splice_sites pass any filter
-    if (sj_filter != IPX_SJ_CANON) return true;
-    const bool cp = motif & IPX_MOTIF_CANON_P, crc = motif & IPX_MOTIF_CANON_RC;
-    if (strand == '-') return crc;
-    if (strand == '.') return cp || crc;
-    return cp;
 }
 
 // ---- wave-segmented reductions -------------------------------------------------
@@ -343,7 +289,7 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
             bool cnt_it = true;
             if (MODE == 1) {
                 v.m1 = ord;
-                v.m2 = record_passes(IPX_ORD_STRAND(ord), jmotif[jid], sj_filter) ? ord : NONE64;
+                v.m2 = ipx_record_passes(IPX_ORD_STRAND(ord), jmotif[jid], sj_filter) ? ord : NONE64;
                 cnt_it = false;
             } else if (MODE == 2) {
                 const unsigned long long cr = creator[jid];

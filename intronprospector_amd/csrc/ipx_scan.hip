@@ -974,7 +974,22 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
             // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
             // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
-#pragma unroll 1
+            // active junction filter: only records that pass it may stand for others (ScanParams::combine); the
+            // others stay what they are, one read each.  The genome look-ups of all rounds go out together.
+            bool pass_r[CR];
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                pass_r[r] = true;
+                if (p.combine == 2u && k < total) {
+                    const uint4 it = pool_item[k];
+                    const uint32_t px = pool_pay[k].x;
+                    const KeyParts kp = unpack_key(it, p.key);
+                    const uint32_t m = ipx_motif_of(p.genome, p.skip_missing, kp.rank, kp.start, kp.end);
+                    pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
+                }
+            }
+#pragma unroll
             for (uint32_t r = 0; r < CR; ++r) {
                 const uint32_t k = r * BT + t;
                 bool live = k < total;
@@ -982,6 +997,10 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 if (live) { it = pool_item[k]; py = pool_pay[k]; }
                 const uint32_t cat = py.x & 3u;
                 live = live && cat != 3u;
+                if (live && !pass_r[r]) {
+                    live = false;
+                    pool_item[k].w = IPX_CNT_ONE(cat);
+                }
                 unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
                 uint32_t lo = py.z, hi = py.w, cw = IPX_CNT_ONE(cat);
                 bool dead = false;

@@ -200,6 +200,97 @@ class JunctionsExtractor:
             pass
 
 
+def _table_to_numpy(t):
+    n = t.n_junctions
+    out = {k: _view(getattr(t, k), n, dt) for k, dt in _NP.items()}
+    out["counts"] = _view(t.read_counts, 3 * n, np.uint64).reshape(n, 3)
+    out["hist_begin"] = _view(t.hist_begin, n + 1, np.uint64) if n else np.zeros(1, np.uint64)
+    out["hist_value"] = _view(t.hist_value, t.n_hist, np.uint16)
+    out["hist_count"] = _view(t.hist_count, t.n_hist, np.uint32)
+    out["n_records"] = t.n_records
+    out["n_alignments"] = t.n_alignments
+    return out
+
+
+class JunctionsExtractorGroup:
+    """Several GPUs behind one extractor (ipx_group of include/ipx.h): every pushed batch is spread over the
+    devices by read index, get_junctions() returns ONE table.  A device listed twice shares that GPU between
+    two members (the rehearsal a one-GPU box allows)."""
+
+    def __init__(self, devices, min_anchor_length=8, max_anchor_indel_size=0, min_intron_length=70,
+                 max_intron_length=500000, junction_filter=L.IPX_SJ_NULL, strandness=L.IPX_UNSTRANDED,
+                 excludes=0, skip_missing_targets=False, scope=L.IPX_SCOPE_TARGET, targets=(), genome=None):
+        self.lib = L.load()
+        p = L.Params(min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length,
+                     junction_filter, strandness, excludes, scope, int(bool(skip_missing_targets)), 0)
+        devs = (C.c_int32 * len(devices))(*devices)
+        g = C.c_void_p()
+        rc = self.lib.ipx_group_create(C.byref(p), len(devices), devs, C.byref(g))
+        if rc:
+            raise RuntimeError("ipx_group_create failed with status %d" % rc)
+        self.g = g
+        self.next_read_index = 0
+        if len(targets):
+            arr = (C.c_char_p * len(targets))(*[n.encode() if isinstance(n, str) else n for n in targets])
+            self._check(self.lib.ipx_group_set_targets(self.g, len(targets), arr, None))
+        if genome is not None:
+            names, seqs = genome
+            n = len(names)
+            arr = (C.c_char_p * n)(*[s.encode() for s in names])
+            lens = (C.c_int64 * n)(*[int(t[2]) for t in seqs])
+            two = (C.c_void_p * n)(*[t[0].ctypes.data for t in seqs])
+            msk = (C.c_void_p * n)(*[t[1].ctypes.data for t in seqs])
+            self._check(self.lib.ipx_group_set_genome_2bit(self.g, n, arr, lens, two, msk))
+
+    def uses_rccl(self):
+        return bool(self.lib.ipx_group_uses_rccl(self.g))
+
+    def _check(self, rc):
+        if rc:
+            e = L.Error()
+            self.lib.ipx_group_last_error(self.g, C.byref(e))
+            raise IpxError(rc, e)
+
+    def push(self, batch, base_read_index=None):
+        n = len(batch["tid"])
+        if base_read_index is None:
+            base_read_index = self.next_read_index
+        arrs = {k: np.ascontiguousarray(batch[k], dt) for k, dt in (
+            ("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("xs", np.uint8), ("nh", np.uint8),
+            ("cigar_off", np.uint32), ("n_cigar", np.uint32), ("cigar", np.uint32))}
+        b = L.Batch(n, len(arrs["cigar"]), base_read_index,
+                    *[arrs[k].ctypes.data for k in ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")],
+                    L.IPX_MEM_HOST)
+        self._check(self.lib.ipx_group_push_batch(self.g, C.byref(b)))
+        self.next_read_index = base_read_index + n
+
+    def get_junctions(self):
+        t = L.Table()
+        rc = self.lib.ipx_group_finalize(self.g, C.byref(t))
+        if rc and rc != L.IPX_EDATA:
+            self._check(rc)
+        out = _table_to_numpy(t)
+        if rc == L.IPX_EDATA:
+            e = L.Error()
+            self.lib.ipx_group_last_error(self.g, C.byref(e))
+            out["error"] = IpxError(rc, e)
+        return out
+
+    def clear(self):
+        self._check(self.lib.ipx_group_clear(self.g))
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.lib.ipx_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def expand_histogram(table):
     """CSR histogram -> the sorted uint16 offset multiset, concatenated per junction
     (what Junction::read_offsets holds after calculate_confidence sorted it)."""

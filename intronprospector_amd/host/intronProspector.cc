@@ -91,10 +91,33 @@ struct Options {
     bool skip_missing_targets = false;
     string junction_bed, intron_bed, intron_bed6, intron_call_tsv, debug_trace_tsv, bam_pass_through;
     bool set_XS_strand_tag = false, set_TS_strand_tag = false;
+    std::vector<int> devices;          // --devices (this build only): empty = GPU 0
 };
 
+// "0-7", "0,2,5" or a mix: the HIP device ordinals --devices names, in the order given
+static std::vector<int> parse_devices(const string &spec) {
+    std::vector<int> out;
+    size_t i = 0;
+    while (i < spec.size()) {
+        size_t j = spec.find(',', i);
+        if (j == string::npos) j = spec.size();
+        const string part = spec.substr(i, j - i);
+        const size_t dash = part.find('-');
+        try {
+            if (dash == string::npos) out.push_back(std::stoi(part));
+            else
+                for (int d = std::stoi(part.substr(0, dash)), e = std::stoi(part.substr(dash + 1)); d <= e; ++d) out.push_back(d);
+        } catch (const std::exception &) {
+            cmd_error("invalid --devices value '" + spec + "', expected a list like 0-7 or 0,2,5");
+        }
+        i = j + 1;
+    }
+    if (out.empty()) cmd_error("invalid --devices value '" + spec + "', expected a list like 0-7 or 0,2,5");
+    return out;
+}
+
 static void parse_options(int argc, char *argv[], Options &o) {
-    enum { OPT_XS = 256, OPT_TS = 257 };
+    enum { OPT_XS = 256, OPT_TS = 257, OPT_DEVICES = 258 };
     static const struct option long_options[] = {
         {"help", no_argument, NULL, 'h'}, {"version", no_argument, NULL, 'v'},
         {"unsorted", no_argument, NULL, 'u'},
@@ -117,6 +140,7 @@ static void parse_options(int argc, char *argv[], Options &o) {
         {"debug-trace", required_argument, NULL, 'D'},
         {"set-XS-strand-tag", no_argument, NULL, OPT_XS},
         {"set-TS-strand-tag", no_argument, NULL, OPT_TS},
+        {"devices", required_argument, NULL, OPT_DEVICES},       // not in the reference: GPUs to spread the input over
         {NULL, 0, NULL, 0}};
     // the reference's short-option string (intronProspector.cc:185), quirks included
     const char *short_options = "hvua:i:I:C:s:X:g:S:j:n:b:c:p:D:f:";
@@ -161,6 +185,7 @@ static void parse_options(int argc, char *argv[], Options &o) {
             case 'p': o.bam_pass_through = optarg; break;
             case OPT_XS: o.set_XS_strand_tag = true; break;
             case OPT_TS: o.set_TS_strand_tag = true; break;
+            case OPT_DEVICES: o.devices = parse_devices(optarg); break;
             case 'h': cerr << usage_msg; exit(0);
             case 'v': cerr << "intronProspector 1.4.0 (MI355X junction-extraction build)" << endl; exit(0);
             case '?':
@@ -214,7 +239,7 @@ static void extract_junctions(const Options &o) {
     JunctionsExtractor extractor(o.min_anchor_length, o.max_anchor_indel_size, o.min_intron_length,
                                  o.max_intron_length, o.junction_filter, o.strandness, o.excludes, genome.get(),
                                  o.skip_missing_targets, 0, &std::cerr, trace_fh.get(), o.set_XS_strand_tag,
-                                 o.set_TS_strand_tag);
+                                 o.set_TS_strand_tag, o.devices);
     OutputFiles output(o);
     if (o.bam_files.size() > 1) {                       // :391-401
         for (const string &bam : o.bam_files) {

@@ -19,7 +19,8 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
                                        uint32_t min_intron_length, uint32_t max_intron_length,
                                        JunctionFilter junction_filter, Strandness strandness, unsigned excludes,
                                        Genome *genome, bool skip_missing_targets, int device, std::ostream *warn,
-                                       std::ostream *trace_fh, bool set_XS_strand_tag, bool set_TS_strand_tag)
+                                       std::ostream *trace_fh, bool set_XS_strand_tag, bool set_TS_strand_tag,
+                                       const std::vector<int> &devices)
     : genome_(genome), skip_missing_targets_(skip_missing_targets), warn_(warn), trace_fh_(trace_fh),
       set_xs_(set_XS_strand_tag), set_ts_(set_TS_strand_tag) {
     ipx_params p{};
@@ -34,11 +35,20 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
     // concatenated target vector are folded here, rows are put in std::map order on the host.
     p.scope = IPX_SCOPE_TARGET;
     p.skip_missing_targets = skip_missing_targets ? 1 : 0;
-    p.device = device;
-    int rc = ipx_create(&p, &h_);
+    p.device = devices.empty() ? device : devices[0];
+    int rc;
+    if (devices.size() > 1) {
+        // the trace and the strand tags walk one device's record list in input order
+        if (trace_fh_ || set_xs_ || set_ts_)
+            throw std::invalid_argument("--devices with more than one GPU cannot be combined with --debug-trace or the strand-tag options");
+        std::vector<int32_t> devs(devices.begin(), devices.end());
+        rc = ipx_group_create(&p, (uint32_t)devs.size(), devs.data(), &g_);
+    } else {
+        rc = ipx_create(&p, &h_);
+    }
     if (rc == IPX_ENODEVICE)
         throw std::runtime_error("no MI355X (gfx950) device available: this build has no CPU path");
-    if (rc != IPX_OK) throw std::runtime_error("ipx_create failed");
+    if (rc != IPX_OK) throw std::runtime_error(g_ || devices.size() > 1 ? "ipx_group_create failed" : "ipx_create failed");
     // the trace and the strand tags walk the single junction records (export_records)
     if (trace_fh_ || set_xs_ || set_ts_) {
         rc = ipx_set_option(h_, IPX_OPT_COMBINE, 0);
@@ -55,18 +65,21 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
             two[i] = genome_->twobit(i);
             msk[i] = genome_->mask(i);
         }
-        rc = ipx_set_genome_2bit(h_, (uint32_t)n, names.data(), lens.data(), two.data(), msk.data());
+        rc = g_ ? ipx_group_set_genome_2bit(g_, (uint32_t)n, names.data(), lens.data(), two.data(), msk.data())
+                : ipx_set_genome_2bit(h_, (uint32_t)n, names.data(), lens.data(), two.data(), msk.data());
         if (rc != IPX_OK) throw_last_error(rc);
     }
 }
 
 JunctionsExtractor::~JunctionsExtractor() {
     if (h_) ipx_destroy(h_);
+    if (g_) ipx_group_destroy(g_);
 }
 
 void JunctionsExtractor::throw_last_error(int status) {
     ipx_error e;
-    ipx_last_error(h_, &e);
+    if (g_) ipx_group_last_error(g_, &e);
+    else ipx_last_error(h_, &e);
     const std::string msg = e.detail[0] ? std::string(e.detail) : ("ipx status " + std::to_string(status));
     if (status == IPX_EDATA) {
         switch (e.kind) {
@@ -92,7 +105,8 @@ void JunctionsExtractor::open(const std::string &bam) {
     }
     std::vector<const char *> names(targets_.size());
     for (size_t i = 0; i < targets_.size(); ++i) names[i] = targets_[i].c_str();
-    int rc = ipx_set_targets(h_, (uint32_t)names.size(), names.data(), nullptr);
+    int rc = g_ ? ipx_group_set_targets(g_, (uint32_t)names.size(), names.data(), nullptr)
+                : ipx_set_targets(h_, (uint32_t)names.size(), names.data(), nullptr);
     if (rc != IPX_OK) throw_last_error(rc);
     if (trace_fh_)          // junctions_extractor.cc:579-584 (nine names over ten columns, as there)
         *trace_fh_ << "chrom" << "\t" << "intron_start" << "\t" << "intron_end" << "\t" << "qname" << "\t" << "flag" << "\t"
@@ -161,7 +175,7 @@ void JunctionsExtractor::flush_batch() {
     b.tid = b_tid_.data(); b.pos = b_pos_.data(); b.flag = b_flag_.data(); b.xs = b_xs_.data();
     b.nh = b_nh_.data(); b.cigar_off = b_off_.data(); b.n_cigar = b_nc_.data(); b.cigar = b_cigar_.data();
     b.memory = IPX_MEM_HOST;
-    int rc = ipx_push_batch(h_, &b);
+    int rc = g_ ? ipx_group_push_batch(g_, &b) : ipx_push_batch(h_, &b);
     next_read_index_ += b.n_alignments;
     b_tid_.clear(); b_pos_.clear(); b_flag_.clear(); b_xs_.clear(); b_nh_.clear();
     b_off_.clear(); b_nc_.clear(); b_cigar_.clear();
@@ -213,7 +227,7 @@ static char complement(char c) {
 void JunctionsExtractor::finalize_table() {
     flush_batch();
     ipx_table t;
-    int rc = ipx_finalize(h_, IPX_MEM_HOST, &t);
+    int rc = g_ ? ipx_group_finalize(g_, &t) : ipx_finalize(h_, IPX_MEM_HOST, &t);
     if (rc != IPX_OK) throw_last_error(rc);
     table_.clear();
     table_.reserve(t.n_junctions);
@@ -376,7 +390,7 @@ void JunctionsExtractor::clear() {
     ijunc_ += (uint32_t)table_.size();
     table_.clear();
     table_valid_ = true;          // an empty table is the table of no records
-    int rc = ipx_clear(h_);
+    int rc = g_ ? ipx_group_clear(g_) : ipx_clear(h_);
     if (rc != IPX_OK) throw_last_error(rc);
     trace_qname_.clear();
     trace_flag_.clear();

@@ -45,7 +45,8 @@ public:
                        uint32_t max_intron_length, JunctionFilter junction_filter, Strandness strandness,
                        unsigned excludes, Genome *genome, bool skip_missing_targets, int device = 0,
                        std::ostream *warn = &std::cerr, std::ostream *trace_fh = nullptr,
-                       bool set_XS_strand_tag = false, bool set_TS_strand_tag = false);
+                       bool set_XS_strand_tag = false, bool set_TS_strand_tag = false,
+                       const std::vector<int> &devices = std::vector<int>());
     ~JunctionsExtractor();
     JunctionsExtractor(const JunctionsExtractor &) = delete;
     JunctionsExtractor &operator=(const JunctionsExtractor &) = delete;
@@ -64,7 +65,10 @@ public:
     uint64_t alignments_processed() const { return next_read_index_; }
 
 private:
+    // one GPU (h_) or several behind one ipx_group (g_, --devices): the alignments of every batch are
+    // spread over the group's GPUs by read index, the junction records meet by key range over RCCL
     ipx_handle *h_ = nullptr;
+    ipx_group *g_ = nullptr;
     Genome *genome_;
     bool skip_missing_targets_;
     std::ostream *warn_;

@@ -1,0 +1,133 @@
+"""GPU: ipx_group (include/ipx.h) -- several GPUs behind one extractor, through the C ABI.  On the one-GPU
+test box two members share the GPU (the exchange then runs over peer copies), and a group of one member is
+sent through the exchange with IPX_GROUP_FORCE_EXCHANGE=1 so that the RCCL calls themselves run."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.oracle_binding import Oracle, OracleError
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle(batch, names, fasta=None, **params):
+    ora = Oracle(targets=names, genome_fasta=fasta, **params)
+    err = None
+    try:
+        ora.process(batch)
+    except OracleError as e:
+        err = e
+    tab = ora.table()
+    ora.close()
+    return tab, err
+
+
+@pytest.mark.parametrize("members,genome", [(2, False), (3, False), (2, True)])
+def test_group_of_members_sharing_the_gpu_equals_oracle(members, genome, oracle_lib):
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    params, fasta, gen2, fetch = {}, None, None, None
+    if genome:
+        batch, names, gen = synth.short_reads(80_000, seed=61, n_targets=4, target_len=2_800_000, n_sites=900, genome=True)
+        fasta = os.path.join(tempfile.mkdtemp(), "g.fa")
+        gen.write_fasta(fasta)
+        params = {"junction_filter": 2}
+        gen2 = (gen.names, [(t, m, len(s)) for (t, m), s in zip(gen.twobit(), gen.seqs)])
+        fetch = lambda tid, s, e: bytes([gen.seqs[tid][s], gen.seqs[tid][s + 1], gen.seqs[tid][e - 2], gen.seqs[tid][e - 1]])
+    else:
+        batch, names, _ = synth.short_reads(80_000, seed=62, n_targets=4, target_len=2_800_000, n_sites=900)
+    grp = ipa.JunctionsExtractorGroup([0] * members, targets=names, genome=gen2, **params)
+    assert not grp.uses_rccl()
+    n = len(batch["tid"])
+    for a, b in ((0, n // 3), (n // 3, n)):                       # two pushes, each spread over the members
+        grp.push(synth.slice_batch(batch, a, b))
+    dev = grp.get_junctions()
+    ref, err = _oracle(batch, names, fasta, **params)
+    assert err is None and "error" not in dev
+    helpers.compare_tables(dev, ref, fetch)
+    assert dev["n_alignments"] == n
+    # a second run on the same group (clear keeps targets, genome, splitters)
+    grp.clear()
+    grp.push(batch, base_read_index=0)
+    helpers.compare_tables(grp.get_junctions(), ref, fetch)
+    grp.close()
+
+
+def test_group_raises_the_earliest_error(oracle_lib):
+    """junctions_extractor.cc:73-74,312-313: a 'P' operation in the second member's range, a spliced FUNMAP read
+    in the first one's: the group reports what the reference's loop would have thrown first"""
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(40_000, seed=63, n_targets=4, target_len=2_800_000, n_sites=700)
+    n = len(batch["tid"])
+    plain = np.nonzero((batch["n_cigar"] == 3) & (batch["flag"] == 0) & (batch["nh"] == 1))[0]
+    i0 = int(plain[(plain > 100) & (plain < n // 2 - 100)][3])
+    i1 = int(plain[plain > n // 2 + 100][3])
+    batch["flag"][i0] |= 0x4
+    w = int(batch["cigar_off"][i1])
+    batch["cigar"][w] = (batch["cigar"][w] & ~np.uint32(0xf)) | np.uint32(6)
+    _, err = _oracle(batch, names)
+    assert err is not None and err.index == i0
+    grp = ipa.JunctionsExtractorGroup([0, 0], targets=names)
+    grp.push(batch)
+    dev = grp.get_junctions()
+    grp.close()
+    assert "error" in dev and str(dev["error"]) == err.msg and dev["error"].read_index == i0
+    # only the later one left: now that is the run's error
+    batch["flag"][i0] &= ~np.uint16(0x4)
+    _, err = _oracle(batch, names)
+    grp = ipa.JunctionsExtractorGroup([0, 0], targets=names)
+    grp.push(batch)
+    dev = grp.get_junctions()
+    grp.close()
+    assert err.index == i1 and str(dev["error"]) == err.msg and dev["error"].read_index == i1
+
+
+def test_group_of_one_runs_the_exchange_over_rccl(oracle_lib):
+    """the RCCL leg (ncclCommInitAll, grouped ncclSend / ncclRecv to itself) in its own process"""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch            # the HIP runtime and RCCL torch brings along are the ones libipx binds to
+import intronprospector_amd as ipa
+from intronprospector_amd import synth
+from tests import helpers
+from tests.oracle_binding import Oracle
+batch, names, _ = synth.short_reads(60_000, seed=64, n_targets=4, target_len=2_800_000, n_sites=800)
+grp = ipa.JunctionsExtractorGroup([0], targets=names)
+assert grp.uses_rccl()
+grp.push(batch)
+dev = grp.get_junctions()
+ora = Oracle(targets=names); ora.process(batch); ref = ora.table(); ora.close()
+helpers.compare_tables(dev, ref)
+grp.close()
+print("rccl-exchange-ok", len(ref["intron_start"]))
+""" % ROOT
+    env = dict(os.environ, IPX_GROUP_FORCE_EXCHANGE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-exchange-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_cli_devices_option(oracle_cli):
+    """intronProspector --devices=0,0: same bytes as the single-GPU command line"""
+    from tests import bamio          # noqa: F401  (the SAM fixtures are text)
+    exe = os.path.join(ROOT, "intronprospector_amd", "bin", "intronProspector")
+    sam = os.path.join(ROOT, "tests", "golden", "input", "test_basic.sam")
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for tag, extra in (("one", []), ("two", ["--devices=0,0"])):
+            tsv, bed = os.path.join(d, tag + ".tsv"), os.path.join(d, tag + ".bed")
+            r = subprocess.run([exe, "--min-confidence-score=0.0", "-c", tsv, "-j", bed] + extra + [sam],
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            outs.append((open(tsv).read(), open(bed).read()))
+        assert outs[0] == outs[1] and len(outs[0][0]) > 500
+        exp = open(os.path.join(ROOT, "tests", "golden", "expected", "testBasic1.introns.tsv")).read()
+        assert outs[1][0] == exp

@@ -580,7 +580,8 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     // record must not straddle the creator: only records that pass the filter themselves are merged (the
     // creator is the first of those, so a group of them lies wholly at or after it), the others stay single.
     // IPX_COMBINE=0 in the environment switches it off (tests compare both).
-    static const bool combine_env = [] { const char *e = getenv("IPX_COMBINE"); return !(e && e[0] == '0'); }();
+    const char *combine_e = getenv("IPX_COMBINE");                 // read per push: a test switches it between runs
+    const bool combine_env = !(combine_e && combine_e[0] == '0');
     const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
     sp.combine = (h->opt_combine && combine_env) ? (filter_active ? 2u : 1u) : 0u;
     sp.skip_missing = h->params.skip_missing_targets;

@@ -545,3 +545,36 @@ def test_per_operation_scan_kernel_matches_oracle(monkeypatch):
     t = ex.get_junctions()
     assert t["error"].kind == 5 and "outside the batch" in t["error"].detail
     ex.close()
+
+
+@pytest.mark.parametrize("max_indel", [0, 3, 36])
+def test_two_speed_long_scan_matches_oracle(max_indel, monkeypatch):
+    """k_scan_long2 (IPX_LONG=2): plain chunks on the fast path, everything else through the op-by-op turn"""
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_LONG", "2")
+    batch, names, _ = synth.long_reads(3000, seed=71, n_targets=2, target_len=9_000_000, n_transcripts=60)
+    dev, ora, err = _run_both(batch, names, {"max_anchor_indel_size": max_indel}, n_push=2)
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
+def test_combiner_on_and_off_give_the_same_table(monkeypatch):
+    """IPX_COMBINE=0: every junction record reaches the sort on its own; the table must not notice"""
+    import hashlib
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(150_000, seed=72, n_targets=3, target_len=3_000_000, n_sites=300)
+    digests, n_rec = [], []
+    for env in ("1", "0"):
+        monkeypatch.setenv("IPX_COMBINE", env)
+        ex = _extractor(targets=names)
+        ex.push(batch)
+        n_rec.append(ex.records_pending())
+        t = ex.get_junctions()
+        ex.close()
+        h = hashlib.sha256()
+        for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc", "counts",
+                  "hist_begin", "hist_value", "hist_count", "creator_order"):
+            h.update(np.ascontiguousarray(t[k]).tobytes())
+        digests.append((h.hexdigest(), t["n_records"]))
+    assert digests[0] == digests[1]
+    assert n_rec[0] * 3 < n_rec[1] == digests[1][1]        # hot junctions: far fewer records leave the scan

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libipx.so")
+LIB_PATH = os.environ.get("IPX_LIB_PATH") or os.path.join(HERE, "libipx.so")     # IPX_LIB_PATH: an instrumented build (profiles/)
 
 IPX_OK, IPX_EINVAL, IPX_ENODEVICE, IPX_ENOMEM, IPX_EDEVICE, IPX_EDATA = range(6)
 IPX_MEM_HOST, IPX_MEM_DEVICE = 0, 1

@@ -699,6 +699,9 @@ __global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n,
     bool in_a = false, in_b = false;              // the landing register holds a chunk of this lane
     uint4 (*const my_ring)[64] = ring_s[wave];
     uint32_t idle_turns = 0;                      // turns in a row without a lane on the fast path (wave-uniform)
+#ifdef IPX_LONG2_STATS
+    uint32_t st_turns = 0, st_slow = 0, st_simple = 0, st_wait = 0, st_drain = 0, st_starved = 0, st_active = 0;
+#endif
     uint32_t state = ST_LIMBO;
     uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;          // offsets from the alignment's pos
     uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
@@ -959,11 +962,19 @@ __global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n,
                 cur += 1u;
             }
             // a lane that has finished its alignment keeps its last junction until a drain: do not let it sit idle
+#ifdef IPX_LONG2_STATS
+            st_turns++; st_simple += __popcll(ipx_ballot(simple)); st_active += __popcll(ipx_ballot(active));
+            st_starved += __popcll(ipx_ballot(active && !have));
+            if (ipx_ballot(pending && !active)) st_drain++;
+#endif
             if (ipx_ballot(pending && !active)) drain();
             // (4) the op-by-op walk for the lanes that wait: when enough of them do, or when nobody else moves
             const unsigned long long wm = ipx_ballot(waiting), sm = ipx_ballot(simple);
             idle_turns = sm ? 0u : idle_turns + 1u;
             if (wm && ((uint32_t)__popcll(wm) >= LONG2_SLOW_AT || idle_turns >= 3u)) {
+#ifdef IPX_LONG2_STATS
+                st_slow++; st_wait += __popcll(wm);
+#endif
                 step(q.x, waiting);
                 step(q.y, waiting);
                 step(q.z, waiting);
@@ -973,6 +984,11 @@ __global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n,
         }
     }
     if (pool_n) flush();
+#ifdef IPX_LONG2_STATS
+    if (lane == 0 && (gw % 997) == 0)
+        printf("wave %llu: turns %u slow %u simple-lanes %u active-lanes %u starved %u waiting-at-slow %u drains %u\n",
+               (unsigned long long)gw, st_turns, st_slow, st_simple, st_active, st_starved, st_wait, st_drain);
+#endif
 
     unsigned long long e = my_err;
     for (int d = 32; d >= 1; d >>= 1) {

@@ -215,6 +215,19 @@ int ipx_reserve(ipx_handle *h, uint64_t n_alignments, uint64_t n_cigar_words, ui
  * the handle.  Batch memory is borrowed until the call returns. */
 int ipx_push_batch(ipx_handle *h, const ipx_batch *batch);
 
+/* The same, overlapped with the caller's own work: ipx_push_batch_async returns as soon as the copies to the
+ * device and the scan are QUEUED on the handle's stream; the batch memory stays borrowed until ipx_sync (or
+ * any other call on the handle, each of which first books the batch in flight) returns.  At most one batch is
+ * in flight: a second ipx_push_batch_async first completes the first.  For the copies to run asynchronously
+ * and at full PCIe rate the batch arrays should live in pinned host memory from ipx_host_alloc: the caller
+ * fills one set of arrays while the device reads the other (host/junctions_extractor.cc does that).
+ * Stands for the same process_alignment loop (junctions_extractor.cc:533-549,656-664). */
+int ipx_push_batch_async(ipx_handle *h, const ipx_batch *batch);
+int ipx_sync(ipx_handle *h);
+/* pinned (page-locked) host memory, hipHostMalloc / hipHostFree */
+int ipx_host_alloc(void **out, size_t bytes);
+int ipx_host_free(void *p);
+
 /* Sort + reduce every record pushed since the last ipx_clear into the junction
  * table.  memory selects where the returned arrays live.  If the input raised a
  * reference exception the call returns IPX_EDATA and ipx_last_error() tells

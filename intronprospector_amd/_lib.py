@@ -28,6 +28,7 @@ SYMBOLS = [
     "ipx_group_create", "ipx_group_destroy", "ipx_group_set_targets", "ipx_group_set_genome_2bit",
     "ipx_group_set_option", "ipx_group_push_batch", "ipx_group_finalize", "ipx_group_clear",
     "ipx_group_last_error", "ipx_group_uses_rccl",
+    "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -97,6 +98,10 @@ def load():
     lib.ipx_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.ipx_set_option.argtypes = [vp, C.c_int32, C.c_int64]
     lib.ipx_push_batch.argtypes = [vp, C.POINTER(Batch)]
+    lib.ipx_push_batch_async.argtypes = [vp, C.POINTER(Batch)]
+    lib.ipx_sync.argtypes = [vp]
+    lib.ipx_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.ipx_host_free.argtypes = [vp]
     lib.ipx_finalize.argtypes = [vp, C.c_int32, C.POINTER(Table)]
     lib.ipx_clear.argtypes = [vp]
     lib.ipx_last_error.argtypes = [vp, C.POINTER(Error)]

@@ -96,6 +96,17 @@ struct ProfScope {
     ~ProfScope() { g_prof = nullptr; }
 };
 
+// a batch whose copies and scan are queued but not yet booked (ipx_push_batch_async)
+struct PendingPush {
+    bool active = false;
+    ipx_batch db{};              // the batch as the device sees it (staged copy or the caller's device arrays)
+    uint64_t n = 0, nw = 0;
+    ScanParams sp{};
+    Counters before{};           // counters to return to if the scan has to be repeated
+    bool use_ops = false, use_stripes = true;
+    int attempt = 0;
+};
+
 struct ipx_handle {
     ipx_params params{};
     Profiler prof;
@@ -139,6 +150,10 @@ struct ipx_handle {
     ipx_error err{};
     float push_ms = 0.f, fin_ms = 0.f;
     bool fin_timing_pending = false;
+    PendingPush pending;
+    // a read-back that was begun but not yet waited for (read_back_begin / read_back_end)
+    uint32_t rb_seq = 0, rb_words = 0;
+    bool rb_by_copy = false;
 };
 
 namespace {
@@ -201,26 +216,44 @@ __global__ void k_publish(const uint32_t *__restrict__ a, uint32_t na, const uin
         if (e__ != hipSuccess) return fail_hip(h, e__, #call, __LINE__); \
     } while (0)
 
-// words a[0..na) and b[0..nb) (device) -> dst (host) once everything queued on the stream before is done
-int read_back(ipx_handle *h, void *dst, const void *a, uint32_t na, const void *b = nullptr, uint32_t nb = 0) {
+// words a[0..na) and b[0..nb) (device) -> host once everything queued on the stream before is done; in two
+// halves so that a caller can leave between them (ipx_push_batch_async): begin queues the publication,
+// end waits for it and copies the words to dst.  One read-back at a time.
+int read_back_begin(ipx_handle *h, const void *a, uint32_t na, const void *b = nullptr, uint32_t nb = 0) {
     static const bool by_copy = [] { const char *e = getenv("IPX_SYNC"); return e && (e[0] == 'b' || e[0] == 'c'); }();
-    if (by_copy || na + nb > MAIL_WORDS) {
-        if (na) HIPCHK(hipMemcpyAsync(dst, a, (size_t)na * 4, hipMemcpyDeviceToHost, h->stream));
-        if (nb) HIPCHK(hipMemcpyAsync((uint32_t *)dst + na, b, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(ipx_stream_wait(h->stream));
+    h->rb_words = na + nb;
+    h->rb_by_copy = by_copy || na + nb > MAIL_WORDS;
+    if (h->rb_by_copy) {
+        if (na) HIPCHK(hipMemcpyAsync(h->pin_small, a, (size_t)na * 4, hipMemcpyDeviceToHost, h->stream));
+        if (nb) HIPCHK(hipMemcpyAsync((uint32_t *)h->pin_small + na, b, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
         return IPX_OK;
     }
-    const uint32_t seq = ++h->mail_seq;
+    h->rb_seq = ++h->mail_seq;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(MAIL_WORDS), 0, h->stream, (const uint32_t *)a, na, (const uint32_t *)b, nb,
-                       h->mail_dev, seq);
+                       h->mail_dev, h->rb_seq);
     HIPCHK(hipGetLastError());
+    return IPX_OK;
+}
+
+int read_back_end(ipx_handle *h, void *dst) {
+    if (h->rb_by_copy) {
+        HIPCHK(ipx_stream_wait(h->stream));
+        if (dst != h->pin_small) memcpy(dst, h->pin_small, (size_t)h->rb_words * 4);
+        return IPX_OK;
+    }
     bool arrived = false;
     for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
-        if (__atomic_load_n(&h->mail_host[MAIL_SEQ], __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+        if (__atomic_load_n(&h->mail_host[MAIL_SEQ], __ATOMIC_ACQUIRE) == h->rb_seq) { arrived = true; break; }
     }
     if (!arrived) HIPCHK(hipStreamSynchronize(h->stream));          // reports the fault, if that is what happened
-    memcpy(dst, h->mail_host, (size_t)(na + nb) * 4);
+    memcpy(dst, h->mail_host, (size_t)h->rb_words * 4);
     return IPX_OK;
+}
+
+int read_back(ipx_handle *h, void *dst, const void *a, uint32_t na, const void *b = nullptr, uint32_t nb = 0) {
+    int rc = read_back_begin(h, a, na, b, nb);
+    if (rc) return rc;
+    return read_back_end(h, dst);
 }
 
 int ensure(ipx_handle *h, DevBuf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0) {
@@ -381,6 +414,8 @@ GenomeDev genome_dev(const ipx_handle *h) {
 
 extern "C" {
 
+static int push_complete(ipx_handle *h);      // books a batch that ipx_push_batch_async left in flight
+
 uint32_t ipx_abi_version(void) { return IPX_ABI_VERSION; }
 
 int ipx_create(const ipx_params *params, ipx_handle **out) {
@@ -432,6 +467,7 @@ int ipx_destroy(ipx_handle *h) {
     if (!h) return IPX_OK;
     (void)hipSetDevice(h->params.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->pending.active = false;
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
@@ -450,6 +486,7 @@ int ipx_destroy(ipx_handle *h) {
 
 int ipx_set_targets(ipx_handle *h, uint32_t n, const char *const *names, const int64_t *lengths) {
     if (!h || (n && !names)) return IPX_EINVAL;
+    { const int prc = push_complete(h); if (prc) return prc; }
     if (h->n_records) {
         // Records already carry key ranks.  In target scope rank == tid, so a list that only
         // APPENDS targets (the reference's save_targets on a further open()) keeps them valid.
@@ -472,6 +509,7 @@ int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names
                         const uint8_t *const *twobit, const uint8_t *const *mask) {
     if (!h) return IPX_EINVAL;
     if (n_seqs && (!names || !lengths || !twobit || !mask)) return IPX_EINVAL;
+    { const int prc = push_complete(h); if (prc) return prc; }
     // pending records were combined (or not) according to the genome that was set when they were pushed
     if (h->n_records) return fail(h, IPX_EINVAL, "ipx_set_genome_2bit with records pending%s%ld", "", 0);
     (void)hipSetDevice(h->params.device);
@@ -520,18 +558,42 @@ int ipx_reserve(ipx_handle *h, uint64_t n_alignments, uint64_t n_cigar_words, ui
     return IPX_OK;
 }
 
-int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
-    if (!h || !b) return IPX_EINVAL;
-    (void)hipSetDevice(h->params.device);
+// ---- ipx_push_batch, split in two so that the caller can overlap its own work (decoding the next batch)
+// with the copy and the scan: push_begin queues the H2D copies, the scan and the publication of its counters;
+// push_complete waits for them, runs the second stage if the scan listed alignments for it, repeats the scan
+// if the record arrays were too small, and books the batch.  ipx_push_batch = begin + complete;
+// ipx_push_batch_async = complete(previous) + begin; every other entry point completes a pending push first.
+static int launch_scan_attempt(ipx_handle *h) {
+    PendingPush &pp = h->pending;
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    if (pp.use_ops)
+        HIPCHK(ipx_launch_scan_ops(h->stream, pp.sp, pp.db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                                   h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap,
+                                   h->counters.as<Counters>()));
+    else
+        HIPCHK(ipx_launch_scan(h->stream, pp.sp, pp.db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                               h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
+                               h->n_records, pp.use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
+                               h->defer.as<uint32_t>()));
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    // [defer count, -, merged records (64 bit)]: IPX_CNT_DEFER and IPX_CNT_MERGED are neighbours
+    const uint32_t *defer_n_dev = reinterpret_cast<const uint32_t *>(h->counters.as<char>() + IPX_CNT_DEFER);
+    return read_back_begin(h, h->counters.p, sizeof(Counters) / 4, defer_n_dev, 4);
+}
+
+static int push_begin(ipx_handle *h, const ipx_batch *b) {
     const uint64_t n = b->n_alignments, nw = b->n_cigar_words;
-    if (n == 0) return IPX_OK;
     if (!b->tid || !b->pos || !b->flag || !b->xs || !b->nh || !b->cigar_off || !b->n_cigar || (nw && !b->cigar))
         return fail(h, IPX_EINVAL, "ipx_push_batch: null array%s%ld", "", 0);
     if (b->base_read_index + n > IPX_ORD_MAX_READ)
         return fail(h, IPX_EINVAL, "read index beyond 2^34-1%s%ld", "", 0);
     if (nw >= (1ull << 32)) return fail(h, IPX_EINVAL, "more than 2^32-1 CIGAR words in one batch%s%ld", "", 0);
     int rc;
-    ipx_batch db = *b;
+    PendingPush &pp = h->pending;
+    pp.db = *b;
+    pp.n = n;
+    pp.nw = nw;
     if (b->memory == IPX_MEM_HOST) {
         // one staging buffer, 256-byte aligned sections
         auto al = [](uint64_t x) { return (x + 255) & ~255ull; };
@@ -548,6 +610,7 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
         HIPCHK(hipMemcpyAsync(s + o_off, b->cigar_off, n * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(s + o_nc, b->n_cigar, n * 4, hipMemcpyHostToDevice, h->stream));
         if (nw) HIPCHK(hipMemcpyAsync(s + o_cig, b->cigar, nw * 4, hipMemcpyHostToDevice, h->stream));
+        ipx_batch &db = pp.db;
         db.tid = (const int32_t *)(s + o_tid); db.pos = (const int32_t *)(s + o_pos);
         db.flag = (const uint16_t *)(s + o_flag); db.xs = (const uint8_t *)(s + o_xs);
         db.nh = (const uint8_t *)(s + o_nh); db.cigar_off = (const uint32_t *)(s + o_off);
@@ -563,7 +626,8 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     uint64_t want = h->n_records + std::min(upper, guess);
     if ((rc = grow_records(h, want))) return rc;
 
-    ScanParams sp{};
+    ScanParams &sp = pp.sp;
+    sp = ScanParams{};
     sp.min_anchor_length = h->params.min_anchor_length;
     sp.max_anchor_indel_size = h->params.max_anchor_indel_size;
     sp.min_intron_length = h->params.min_intron_length;
@@ -587,44 +651,46 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
     sp.skip_missing = h->params.skip_missing_targets;
     if (filter_active) sp.genome = genome_dev(h);
 
-    ProfScope prof_scope(&h->prof);
     // state to return to if a scan has to be repeated
-    Counters before{};
+    Counters &before = pp.before;
+    before = Counters{};
     before.n_records = h->n_records;
     before.err_word = h->err_word_host;
     for (int k = 0; k < 3; ++k) { before.key_or[k] = h->key_or[k]; before.key_and[k] = h->key_and[k]; }
-    bool use_ops = !h->force_lane_scan;
-    bool use_stripes = true;
+    pp.use_ops = !h->force_lane_scan;
+    pp.use_stripes = true;
+    pp.attempt = 0;
     // list of the alignments k_scan_short hands on to k_scan_rest (at most all of them)
-    if ((rc = ensure(h, h->defer, (size_t)db.n_alignments * sizeof(uint32_t) + 256))) return rc;
-    for (int attempt = 0; attempt < 5; ++attempt) {
-        ipx_prof_mark(h->stream, IPXK_BEGIN);
-        HIPCHK(hipEventRecord(h->ev[0], h->stream));
-        if (use_ops)
-            HIPCHK(ipx_launch_scan_ops(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                       h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap,
-                                       h->counters.as<Counters>()));
-        else
-            HIPCHK(ipx_launch_scan(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                   h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
-                                   h->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
-                                   h->defer.as<uint32_t>()));
-        HIPCHK(hipEventRecord(h->ev[1], h->stream));
-        const uint32_t *defer_n_dev = reinterpret_cast<const uint32_t *>(h->counters.as<char>() + IPX_CNT_DEFER);
-        // [defer count, -, merged records (64 bit)]: IPX_CNT_DEFER and IPX_CNT_MERGED are neighbours
-        if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, defer_n_dev, 4))) return rc;
+    if ((rc = ensure(h, h->defer, (size_t)n * sizeof(uint32_t) + 256))) return rc;
+    ProfScope prof_scope(&h->prof);
+    if ((rc = launch_scan_attempt(h))) return rc;
+    pp.active = true;
+    return IPX_OK;
+}
+
+static int push_complete(ipx_handle *h) {
+    PendingPush &pp = h->pending;
+    if (!pp.active) return IPX_OK;
+    pp.active = false;
+    (void)hipSetDevice(h->params.device);
+    ProfScope prof_scope(&h->prof);
+    const ipx_batch &db = pp.db;
+    const ScanParams &sp = pp.sp;
+    int rc;
+    for (;;) {
+        if ((rc = read_back_end(h, h->pin_small))) return rc;
         h->prof.collect();
         const Counters *c = (const Counters *)h->pin_small;
         const uint32_t *tail4 = (const uint32_t *)h->pin_small + sizeof(Counters) / 4;
-        const uint64_t merged = use_ops ? 0ull : ((uint64_t)tail4[2] | ((uint64_t)tail4[3] << 32));
-        const bool layout_bad = use_ops && c->pad[0] != 0;
+        const uint64_t merged = pp.use_ops ? 0ull : ((uint64_t)tail4[2] | ((uint64_t)tail4[3] << 32));
+        const bool layout_bad = pp.use_ops && c->pad[0] != 0;
         bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
         // second stage: alignments the short-CIGAR kernel only listed (more than 8 ops, overflowing tiles)
-        const uint32_t n_defer = use_ops ? 0u : ((const uint32_t *)h->pin_small)[sizeof(Counters) / 4];
+        const uint32_t n_defer = pp.use_ops ? 0u : tail4[0];
         if (n_defer && !layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             HIPCHK(ipx_launch_scan_rest(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
                                         h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
-                                        c->n_records, use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
+                                        c->n_records, pp.use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
                                         h->defer.as<uint32_t>(), n_defer));
             HIPCHK(hipEventRecord(h->ev[1], h->stream));
             if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
@@ -634,31 +700,69 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
         if (!layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->err_word_host = c->err_word;
-            h->seen_words += nw;
+            h->seen_words += pp.nw;
             h->seen_records += c->n_records - h->n_records;
             h->n_raw += c->n_records - h->n_records + merged;
             h->n_records = c->n_records;
             break;
         }
-        if (attempt == 4) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
+        if (pp.attempt == 4) return fail(h, IPX_EDEVICE, "record capacity still too small after regrow%s%ld", "", 0);
         // Either the per-operation scan cannot walk this CIGAR layout (words not back to back in
         // alignment order): repeat with the lane-per-alignment kernel.  Or the capacity estimate was
         // too small: records beyond it were counted but not stored; make room and scan again.
         const uint64_t need = c->n_records;
-        hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), before);
+        hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), pp.before);
         HIPCHK(hipGetLastError());
-        if (layout_bad) use_ops = false;
-        else if (stripes_bad) use_stripes = false;
+        if (layout_bad) pp.use_ops = false;
+        else if (stripes_bad) pp.use_stripes = false;
         else if ((rc = grow_records(h, need))) return rc;
+        ++pp.attempt;
+        if ((rc = launch_scan_attempt(h))) return rc;
     }
     (void)hipEventElapsedTime(&h->push_ms, h->ev[0], h->ev[1]);
-    h->n_alignments += n;
+    h->n_alignments += pp.n;
+    return IPX_OK;
+}
+
+int ipx_push_batch(ipx_handle *h, const ipx_batch *b) {
+    if (!h || !b) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    int rc = push_complete(h);
+    if (rc) return rc;
+    if (b->n_alignments == 0) return IPX_OK;
+    if ((rc = push_begin(h, b))) return rc;
+    return push_complete(h);
+}
+
+int ipx_push_batch_async(ipx_handle *h, const ipx_batch *b) {
+    if (!h || !b) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    int rc = push_complete(h);              // at most one batch in flight
+    if (rc) return rc;
+    if (b->n_alignments == 0) return IPX_OK;
+    return push_begin(h, b);
+}
+
+int ipx_sync(ipx_handle *h) {
+    if (!h) return IPX_EINVAL;
+    return push_complete(h);
+}
+
+int ipx_host_alloc(void **out, size_t bytes) {
+    if (!out) return IPX_EINVAL;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? IPX_OK : IPX_ENOMEM;
+}
+
+int ipx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
     return IPX_OK;
 }
 
 int ipx_clear(ipx_handle *h) {
     if (!h) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    (void)push_complete(h);                 // whatever the batch in flight held is dropped with the rest
     h->n_records = 0;
     h->n_raw = 0;
     h->n_alignments = 0;
@@ -961,6 +1065,7 @@ static int report_data_error(ipx_handle *h, unsigned long long err_word) {
 int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
     if (!h || !out || (memory != IPX_MEM_HOST && memory != IPX_MEM_DEVICE)) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
     memset(&h->err, 0, sizeof h->err);
     unsigned long long err_word = IPX_ERRW_NONE;
     (void)hipEventRecord(h->ev[2], h->stream);
@@ -1019,6 +1124,7 @@ int ipx_profile_read(const ipx_handle *h, ipx_kernel_stat *out, uint32_t cap, ui
 int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creator, ipx_table *out_all) {
     if (!h || !out_from_creator || !out_all || (memory != IPX_MEM_HOST && memory != IPX_MEM_DEVICE)) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
     memset(&h->err, 0, sizeof h->err);
     unsigned long long err_word = IPX_ERRW_NONE, err2 = IPX_ERRW_NONE;
     (void)hipEventRecord(h->ev[2], h->stream);
@@ -1044,6 +1150,7 @@ int ipx_finalize_shard(ipx_handle *h, int32_t memory, ipx_table *out_from_creato
 // ---- multi-GPU record exchange (ipx_exchange.hip) ------------------------------------
 int ipx_records_pending(const ipx_handle *h, uint64_t *n_records) {
     if (!h || !n_records) return IPX_EINVAL;
+    { const int prc = push_complete(const_cast<ipx_handle *>(h)); if (prc) return prc; }
     *n_records = h->n_records;
     return IPX_OK;
 }
@@ -1067,6 +1174,7 @@ static void unpack_key_host(const uint32_t it[4], const KeyLayout &kl, uint32_t 
 int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64_t *n_records) {
     if (!h || !n_records) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
     const uint64_t n = h->n_records;
     *n_records = n;
     if (n == 0) return IPX_OK;
@@ -1094,6 +1202,7 @@ int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64
 int ipx_records_sample(ipx_handle *h, uint32_t n_samples, uint64_t *out_keys) {
     if (!h || (n_samples && !out_keys) || n_samples > 4096) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
     if (!n_samples) return IPX_OK;
     int rc = ensure(h, h->d_xchg, (size_t)4096 * 8 + 2 * 64 * 8);
     if (rc) return rc;
@@ -1109,6 +1218,7 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
     if (!h || !n_parts || n_parts > 64 || (n_parts > 1 && !splitters) || !counts || (h->n_records && !dst_records))
         return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
     // d_xchg: 4096 sample keys | 64 splitters | 64 part totals | 64 words per partition block
     const uint32_t blocks = ipx_partition_blocks(h->n_records);
     int rc = ensure(h, h->d_xchg, ((size_t)4096 + 2 * 64 + (size_t)blocks * 64) * 8);
@@ -1134,6 +1244,7 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
 int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n_alignments) {
     if (!h || (n && !records)) return IPX_EINVAL;
     (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
     // the handle's own records are replaced; what its scan found wrong with the input stays (err_word):
     // the records this rank scanned went to their key-range owners, their errors did not
     const unsigned long long scan_err = h->err_word_host;

@@ -132,6 +132,8 @@ bool AlnReader::read_sam(AlnRecord &rec) {
             c = e + 1;
         }
     }
+    rec.cig = reinterpret_cast<const uint8_t *>(rec.cigar.data());
+    rec.n_cig = (uint32_t)rec.cigar.size();
     rec.xs = 0;
     rec.nh = 0;
     bool have_xs = false, have_nh = false;
@@ -200,15 +202,32 @@ void AlnReader::parse_bam_header() {
 }
 
 bool AlnReader::read_bam(AlnRecord &rec) {
-    uint8_t w[4];
-    const size_t r = read_some(w, 4);
-    if (r == 0) return false;
-    if (r != 4) throw std::runtime_error("Error reader BAM record: " + path_);
-    uint32_t block = le32(w);
-    if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
-    buf_.resize(block);
-    read_exact(buf_.data(), block, "record");
-    const uint8_t *b = buf_.data();
+    if (pending_advance_) {                  // the previous record was parsed where it lay: release it now
+        bgzf_->advance(pending_advance_);
+        pending_advance_ = 0;
+    }
+    const uint8_t *b = nullptr;
+    uint32_t block = 0;
+    const uint8_t *pk = nullptr;
+    if (bgzf_ && bgzf_->peek(4, &pk)) {
+        block = le32(pk);
+        if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
+        if (bgzf_->peek(4 + (size_t)block, &pk)) {       // the whole record lies in this block: no copy
+            b = pk + 4;
+            pending_advance_ = 4 + (size_t)block;
+        }
+    }
+    if (!b) {
+        uint8_t w[4];
+        const size_t r = read_some(w, 4);
+        if (r == 0) return false;
+        if (r != 4) throw std::runtime_error("Error reader BAM record: " + path_);
+        block = le32(w);
+        if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
+        buf_.resize(block);
+        read_exact(buf_.data(), block, "record");
+        b = buf_.data();
+    }
     rec.tid = (int32_t)le32(b);
     rec.pos = (int32_t)le32(b + 4);
     const uint32_t l_read_name = b[8];
@@ -220,8 +239,8 @@ bool AlnReader::read_bam(AlnRecord &rec) {
     if (keep_qname_) rec.qname.assign((const char *)b + off, l_read_name ? l_read_name - 1 : 0);
     off += l_read_name;
     if (off + 4ull * n_cigar > block) throw std::runtime_error("Error reader BAM record: " + path_);
-    rec.cigar.resize(n_cigar);
-    for (uint32_t i = 0; i < n_cigar; ++i) rec.cigar[i] = le32(b + off + 4 * i);
+    rec.cig = b + off;                       // little-endian words, as the device wants them
+    rec.n_cig = n_cigar;
     off += 4ull * n_cigar;
     off += (l_seq + 1) / 2 + l_seq;
     if (off > block) throw std::runtime_error("Error reader BAM record: " + path_);
@@ -280,9 +299,9 @@ bool AlnReader::read_bam(AlnRecord &rec) {
         off = p + sz;
     }
     // long CIGARs live in the CG tag behind a "<l_seq>S<ref_len>N" placeholder (SAM spec 4.2.2)
-    if (cg && n_cigar == 2 && (rec.cigar[0] & 0xf) == 4 && (rec.cigar[0] >> 4) == l_seq && (rec.cigar[1] & 0xf) == 3) {
-        rec.cigar.resize(cg_n);
-        for (uint32_t i = 0; i < cg_n; ++i) rec.cigar[i] = le32(cg + 4 * i);
+    if (cg && n_cigar == 2 && (rec.cigar_word(0) & 0xf) == 4 && (rec.cigar_word(0) >> 4) == l_seq && (rec.cigar_word(1) & 0xf) == 3) {
+        rec.cig = cg;
+        rec.n_cig = cg_n;
     }
     return true;
 }

@@ -9,6 +9,7 @@
 #ifndef IPX_HOST_ALN_READER_HH
 #define IPX_HOST_ALN_READER_HH
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <memory>
@@ -24,6 +25,11 @@ struct AlnRecord {
     uint16_t flag = 0;
     uint8_t xs = 0;        // 0 = no XS tag, else strand byte ('.' if the tag is not of type A)
     uint8_t nh = 0;        // 0 = no NH / <= 0, 1 = NH == 1, 2 = NH > 1
+    // CIGAR words in BAM packing: n_cig words starting at cig (unaligned; valid until the next read()).
+    // SAM text fills `cigar` and points cig at it; BAM points straight into the inflated block.
+    const uint8_t *cig = nullptr;
+    uint32_t n_cig = 0;
+    uint32_t cigar_word(size_t k) const { uint32_t w; memcpy(&w, cig + 4 * k, 4); return w; }
     std::vector<uint32_t> cigar;
     std::string qname;
     // kept only when the reader was asked to (pass-through): the SAM line without its newline, or
@@ -70,6 +76,7 @@ private:
     bool read_sam(AlnRecord &rec);
     // BAM state
     std::vector<uint8_t> buf_;
+    size_t pending_advance_ = 0;             // bytes of the block the previous record was parsed from in place
     size_t read_some(void *dst, size_t n);
     void read_exact(void *dst, size_t n, const char *what);
     void parse_bam_header();

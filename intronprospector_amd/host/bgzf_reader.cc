@@ -174,6 +174,35 @@ void BgzfReader::worker() {
     inflateEnd(&zs);
 }
 
+bool BgzfReader::peek(size_t n, const uint8_t **p) {
+    Slot &s = ring_[next_consume_ % ring_.size()];
+    if (!cur_valid_) {
+        std::unique_lock<std::mutex> lk(m_);
+        can_consume_.wait(lk, [&] { return s.ready || next_consume_ >= end_seq_ || stop_; });
+        if (!s.ready) return false;                 // end of file
+        if (!s.error.empty()) throw std::runtime_error("Error reader BAM record: " + path_ + " (" + s.error + ")");
+        cur_valid_ = true;
+        cur_off_ = 0;
+    }
+    if (s.out.size() - cur_off_ < n) return false;
+    *p = s.out.data() + cur_off_;
+    return true;
+}
+
+void BgzfReader::advance(size_t n) {
+    Slot &s = ring_[next_consume_ % ring_.size()];
+    cur_off_ += n;
+    if (cur_off_ >= s.out.size()) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            s.ready = false;
+            ++next_consume_;
+        }
+        cur_valid_ = false;
+        can_produce_.notify_all();
+    }
+}
+
 size_t BgzfReader::read(void *dst, size_t n) {
     size_t done = 0;
     while (done < n) {

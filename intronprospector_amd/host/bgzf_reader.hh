@@ -32,6 +32,11 @@ public:
 
     // up to n bytes; 0 at end of file; throws std::runtime_error on a damaged block
     size_t read(void *dst, size_t n);
+    // Zero-copy access for records that lie inside one block (all but one in a few hundred): peek() hands out
+    // a pointer to the next n bytes if the current block holds them all (false: use read(), the bytes straddle
+    // blocks or the input has ended); the pointer stays valid until advance(), which consumes the bytes.
+    bool peek(size_t n, const uint8_t **p);
+    void advance(size_t n);
     unsigned threads() const { return (unsigned)workers_.size(); }
     uint64_t compressed_bytes() const { return compressed_bytes_; }
 

@@ -39,8 +39,8 @@ static int dump_aln(const char *path) {
         printf("@SQ\t%s\t%lld\n", rd.target_names()[i].c_str(), (long long)rd.target_lengths()[i]);
     AlnRecord r;
     while (rd.read(r)) {
-        printf("%d\t%lld\t%u\t%u\t%u\t%zu\t", r.tid, (long long)r.pos, r.flag, r.xs, r.nh, r.cigar.size());
-        for (size_t k = 0; k < r.cigar.size(); ++k) printf(k ? ",%u" : "%u", r.cigar[k]);
+        printf("%d\t%lld\t%u\t%u\t%u\t%zu\t", r.tid, (long long)r.pos, r.flag, r.xs, r.nh, (size_t)r.n_cig);
+        for (size_t k = 0; k < r.n_cig; ++k) printf(k ? ",%u" : "%u", r.cigar_word(k));
         printf("\n");
     }
     return 0;
@@ -181,7 +181,7 @@ static int bench_decode(const char *path, const char *threads) {
     uint64_t n = 0, words = 0, sum = 0;
     while (rd.read(r)) {
         ++n;
-        words += r.cigar.size();
+        words += r.n_cig;
         sum += (uint64_t)r.pos + r.flag + r.nh + r.xs;
     }
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

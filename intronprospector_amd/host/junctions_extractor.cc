@@ -1,5 +1,8 @@
 // junctions_extractor.cc -- see junctions_extractor.hh.
 #include "junctions_extractor.hh"
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
 
 #include <algorithm>
 #include <cctype>
@@ -54,6 +57,7 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
         rc = ipx_set_option(h_, IPX_OPT_COMBINE, 0);
         if (rc != IPX_OK) throw_last_error(rc);
     }
+    { const char *e = getenv("IPX_TIMELINE"); timeline_ = e && e[0] == '1'; }
     if (genome_) {
         const size_t n = genome_->n_seqs();
         std::vector<const char *> names(n);
@@ -72,8 +76,35 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
 }
 
 JunctionsExtractor::~JunctionsExtractor() {
+    if (timeline_)
+        std::cerr << "{\"ipx_timeline\": {\"alignments\": " << next_read_index_ << ", \"pushes\": " << n_push_
+                  << ", \"read_s\": " << t_read_ << ", \"queue_s\": " << t_queue_ << ", \"push_wait_s\": " << t_push_
+                  << ", \"finalize_s\": " << t_finalize_ << ", \"table_to_host_rows_s\": " << t_table_ << "}}" << std::endl;
     if (h_) ipx_destroy(h_);
     if (g_) ipx_group_destroy(g_);
+    for (HostBatch &b : batch_)
+        if (b.mem) ipx_host_free(b.mem);
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// (re)allocate a batch's pinned arrays; the batch must be empty
+void JunctionsExtractor::size_batch(HostBatch &b, size_t cap_aln, size_t cap_words) {
+    if (b.mem) ipx_host_free(b.mem);
+    b = HostBatch();
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_tid = 0, o_pos = al(o_tid + cap_aln * 4), o_flag = al(o_pos + cap_aln * 4), o_xs = al(o_flag + cap_aln * 2),
+                 o_nh = al(o_xs + cap_aln), o_off = al(o_nh + cap_aln), o_nc = al(o_off + cap_aln * 4),
+                 o_cig = al(o_nc + cap_aln * 4), total = al(o_cig + cap_words * 4);
+    if (ipx_host_alloc(&b.mem, total) != IPX_OK) throw std::runtime_error("out of pinned host memory for the alignment batches");
+    char *m = (char *)b.mem;
+    b.tid = (int32_t *)(m + o_tid); b.pos = (int32_t *)(m + o_pos); b.flag = (uint16_t *)(m + o_flag);
+    b.xs = (uint8_t *)(m + o_xs); b.nh = (uint8_t *)(m + o_nh); b.off = (uint32_t *)(m + o_off);
+    b.nc = (uint32_t *)(m + o_nc); b.cigar = (uint32_t *)(m + o_cig);
+    b.cap_aln = cap_aln;
+    b.cap_words = cap_words;
 }
 
 void JunctionsExtractor::throw_last_error(int status) {
@@ -143,42 +174,68 @@ bool JunctionsExtractor::read_align() {
         aln_pending_ = false;
         return true;
     }
+    if (timeline_ && (++tick_ & 63u) == 0) {            // every 64th call is timed, the sums are scaled
+        const double t0 = now_s();
+        const bool ok = reader_->read(aln_buf_);
+        t_read_ += 64.0 * (now_s() - t0);
+        return ok;
+    }
     return reader_->read(aln_buf_);
 }
 
 // process_alignment (junctions_extractor.cc:533-549) is the device's job: queue the record
 void JunctionsExtractor::process_alignment(const AlnRecord &aln) {
+    struct QueueTimer { double &acc; double t0; bool on; ~QueueTimer() { if (on) acc += 64.0 * (now_s() - t0); } }
+        queue_timer{t_queue_, 0.0, timeline_ && (tick_ & 63u) == 0};
+    if (queue_timer.on) queue_timer.t0 = now_s();
     int32_t tid = aln.tid;
     if (tid >= 0 && (size_t)tid < canon_tid_.size()) tid = canon_tid_[tid];
     if (trace_fh_) {
         trace_qname_.push_back(aln.qname);
         trace_flag_.push_back(aln.flag);
     }
-    b_tid_.push_back(tid);
-    b_pos_.push_back((int32_t)aln.pos);
-    b_flag_.push_back(aln.flag);
-    b_xs_.push_back(aln.xs);
-    b_nh_.push_back(aln.nh);
-    b_off_.push_back((uint32_t)b_cigar_.size());
-    b_nc_.push_back((uint32_t)aln.cigar.size());
-    b_cigar_.insert(b_cigar_.end(), aln.cigar.begin(), aln.cigar.end());
+    const size_t nc = aln.n_cig;
+    HostBatch *b = &batch_[cur_];
+    if (b->n == b->cap_aln || b->nw + nc > b->cap_words) {
+        // full: hand it to the device and go on with the other set, grown if the input turns out to be large
+        const size_t had = b->cap_aln;
+        flush_batch();
+        b = &batch_[cur_];
+        size_t want_aln = std::max<size_t>(b->cap_aln, std::min<size_t>(BATCH_ALIGNMENTS, std::max<size_t>(had * 8, 1u << 14)));
+        size_t want_words = std::max<size_t>(std::max(b->cap_words, want_aln * 8), nc);
+        if (want_aln > b->cap_aln || want_words > b->cap_words) size_batch(*b, want_aln, want_words);
+    }
+    const size_t i = b->n++;
+    b->tid[i] = tid;
+    b->pos[i] = (int32_t)aln.pos;
+    b->flag[i] = aln.flag;
+    b->xs[i] = aln.xs;
+    b->nh[i] = aln.nh;
+    b->off[i] = (uint32_t)b->nw;
+    b->nc[i] = (uint32_t)nc;
+    if (nc) memcpy(b->cigar + b->nw, aln.cig, nc * sizeof(uint32_t));
+    b->nw += nc;
     table_valid_ = false;
-    if (b_tid_.size() >= BATCH_ALIGNMENTS || b_cigar_.size() >= (1u << 28)) flush_batch();
 }
 
 void JunctionsExtractor::flush_batch() {
-    if (b_tid_.empty()) return;
+    HostBatch &hb = batch_[cur_];
+    if (hb.n == 0) return;
     ipx_batch b{};
-    b.n_alignments = b_tid_.size();
-    b.n_cigar_words = b_cigar_.size();
+    b.n_alignments = hb.n;
+    b.n_cigar_words = hb.nw;
     b.base_read_index = next_read_index_;
-    b.tid = b_tid_.data(); b.pos = b_pos_.data(); b.flag = b_flag_.data(); b.xs = b_xs_.data();
-    b.nh = b_nh_.data(); b.cigar_off = b_off_.data(); b.n_cigar = b_nc_.data(); b.cigar = b_cigar_.data();
+    b.tid = hb.tid; b.pos = hb.pos; b.flag = hb.flag; b.xs = hb.xs;
+    b.nh = hb.nh; b.cigar_off = hb.off; b.n_cigar = hb.nc; b.cigar = hb.cigar;
     b.memory = IPX_MEM_HOST;
-    int rc = g_ ? ipx_group_push_batch(g_, &b) : ipx_push_batch(h_, &b);
-    next_read_index_ += b.n_alignments;
-    b_tid_.clear(); b_pos_.clear(); b_flag_.clear(); b_xs_.clear(); b_nh_.clear();
-    b_off_.clear(); b_nc_.clear(); b_cigar_.clear();
+    const double t0 = timeline_ ? now_s() : 0.0;
+    // one GPU: the copies and the scan are queued and this set of arrays stays with the device until the NEXT
+    // push (which first completes this one) -- by then the loop has filled the other set
+    int rc = g_ ? ipx_group_push_batch(g_, &b) : ipx_push_batch_async(h_, &b);
+    if (timeline_) { t_push_ += now_s() - t0; ++n_push_; }
+    next_read_index_ += hb.n;
+    hb.n = hb.nw = 0;
+    if (!g_) cur_ ^= 1;
     if (rc != IPX_OK) throw_last_error(rc);
 }
 
@@ -200,7 +257,7 @@ void JunctionsExtractor::identify_junctions_for_target(int target_index) {
         if (pass_through_) {                    // process_target_alignment, :647-650
             if (set_xs_ || set_ts_) {
                 pt_pending_.push_back(aln_buf_);
-                pt_read_index_.push_back(next_read_index_ + b_tid_.size() - 1);
+                pt_read_index_.push_back(next_read_index_ + batch_[cur_].n - 1);
             } else {
                 pass_through_->write(aln_buf_, 0, false, false);
             }
@@ -227,7 +284,11 @@ static char complement(char c) {
 void JunctionsExtractor::finalize_table() {
     flush_batch();
     ipx_table t;
+    const double t0 = timeline_ ? now_s() : 0.0;
     int rc = g_ ? ipx_group_finalize(g_, &t) : ipx_finalize(h_, IPX_MEM_HOST, &t);
+    const double t1 = timeline_ ? now_s() : 0.0;
+    t_finalize_ += t1 - t0;
+    struct RowTimer { double &acc; double t0; bool on; ~RowTimer() { if (on) acc += now_s() - t0; } } row_timer{t_table_, t1, timeline_};
     if (rc != IPX_OK) throw_last_error(rc);
     table_.clear();
     table_.reserve(t.n_junctions);

@@ -82,11 +82,26 @@ private:
     std::unique_ptr<AlnReader> reader_;
     uint32_t ijunc_ = 0;
     uint64_t next_read_index_ = 0;
-    // pending host batch (SoA of include/ipx.h)
-    std::vector<int32_t> b_tid_, b_pos_;
-    std::vector<uint16_t> b_flag_;
-    std::vector<uint8_t> b_xs_, b_nh_;
-    std::vector<uint32_t> b_off_, b_nc_, b_cigar_;
+    // The host batch (SoA of include/ipx.h) lives in PINNED memory, twice: the read loop fills one set of
+    // arrays while the device copies and scans the other (ipx_push_batch_async); a full set is handed over
+    // and the loop goes on with the set whose push has completed by then.  Sets start small (tests read a few
+    // hundred alignments) and grow to BATCH_ALIGNMENTS.
+    struct HostBatch {
+        void *mem = nullptr;                      // one ipx_host_alloc block holding all eight arrays
+        size_t cap_aln = 0, cap_words = 0, n = 0, nw = 0;
+        int32_t *tid = nullptr, *pos = nullptr;
+        uint16_t *flag = nullptr;
+        uint8_t *xs = nullptr, *nh = nullptr;
+        uint32_t *off = nullptr, *nc = nullptr, *cigar = nullptr;
+    };
+    HostBatch batch_[2];
+    int cur_ = 0;
+    void size_batch(HostBatch &b, size_t cap_aln, size_t cap_words);
+    // IPX_TIMELINE=1: where the wall time of the command goes (stderr, one JSON line at destruction)
+    bool timeline_ = false;
+    double t_read_ = 0, t_queue_ = 0, t_push_ = 0, t_finalize_ = 0, t_table_ = 0;
+    uint64_t n_push_ = 0;
+    uint32_t tick_ = 0;
     // finalized table of the records pushed since the last clear()
     bool table_valid_ = false;
     JunctionVector table_;

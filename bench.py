@@ -277,7 +277,9 @@ def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, 
         out.update({
             "kernel": dominant, "kernel_launches_per_step": launches / steps, "kernel_avg_ms": avg_ms,
             "kernel_bytes_per_launch": kb, "kernel_achieved": kb / (avg_ms * 1e-3) / 1e9,
-            "kernel_frac": kb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_traffic": tr.get(dominant),
+            "kernel_frac": kb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # PMC bytes of this kernel class per STEP (all its launches; profiles/traffic.json)
+            "kernel_traffic_step_bytes": tr.get(dominant),
         })
     if stats:
         out["kernels_ms_per_step"] = {k: v[1] / breakdown_steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])}
@@ -354,6 +356,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10 M for S and G, 2 M for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the device-vs-oracle check of a prefix (profiling runs)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` sub-records (L at 2 M, G at 10 M) of the default single-GPU S run")
     ap.add_argument("--shuffle", action="store_true",
@@ -526,7 +529,7 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        if world == 1 and not multi and not args.shuffle:
+        if world == 1 and not multi and not args.shuffle and not args.no_parity:
             try:        # the benchmark's own batch, a prefix of it, device against oracle
                 out["config"]["parity_prefix"] = parity_prefix(kind, batch, names, genome_pack, genome,
                                                                20_000 if kind == "L" else 200_000, local_rank)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per kernel class and per step from two rocprofv3 counter runs (FETCH_SIZE, WRITE_SIZE; they
+cannot share a run), as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts wide
+(16 B per lane) streaming reads at half their bytes -> doubled; WRITE_SIZE as is.  Both are L2 <-> fabric
+requests: Infinity-Cache hits are included, so for working sets below 256 MiB this is an upper bound of HBM traffic.
+
+usage: pmc_traffic.py WORKLOAD STEPS fetch_dir write_dir [traffic.json]
+  STEPS = steps the profiled bench.py ran in all (warm-up + 1 probe + timed + 3 breakdown)
+Updates traffic.json[WORKLOAD] = {class: bytes per STEP (all launches of the class), "step_bytes": ...,
+"launches_per_step": ...}; per-launch figures are in traffic.json["detail"]."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+CLASS = [
+    (r"k_scan_short|k_scan_long|k_scan_rest|k_scan_ops|k_close_|k_cigar_tail", "k_scan"),
+    (r"k_scatter", "k_scatter"), (r"k_hist", "k_hist"), (r"k_binscan", "k_binscan"),
+    (r"k_reduce<1>", "k_reduce_a"), (r"k_reduce", "k_reduce"),
+    (r"k_count_heads", "k_count_heads"), (r"k_write_heads", "k_write_heads"),
+    (r"k_scan_sums|k_scan_top|k_scan_apply", "scan_u32"),
+    (r"k_emit_|k_finish_|k_motif|k_bins|k_rank_|k_publish|k_set_counters|fillBuffer|copyBuffer", "small"),
+]
+
+
+def klass(name):
+    for pat, c in CLASS:
+        if re.search(pat, name):
+            return c
+    return "other"
+
+
+def load(d, counter):
+    fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        raise SystemExit("no counter_collection.csv under " + d)
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = agg[klass(r["Kernel_Name"])]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return agg
+
+
+def main():
+    wl, steps, fdir, wdir = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
+    fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    out, step_bytes, launches = {}, 0.0, 0
+    detail = {}
+    for c in sorted(set(fetch) | set(write)):
+        fkb, fn = fetch.get(c, [0.0, 0])
+        wkb, wn = write.get(c, [0.0, 0])
+        n = max(fn, wn, 1)
+        total = fkb * 1024 * 2 + wkb * 1024          # FETCH_SIZE doubled (gfx950), both in KB
+        out[c] = total / steps
+        detail[c] = {"launches_per_step": n / steps, "fetch_kb_per_launch": fkb / n, "write_kb_per_launch": wkb / n,
+                     "bytes_per_step": total / steps}
+        step_bytes += total / steps
+        launches += n
+    out["step_bytes"] = step_bytes
+    out["launches_per_step"] = launches / steps
+    try:
+        t = json.load(open(path))
+    except Exception:
+        t = {}
+    t[wl] = out
+    t.setdefault("detail", {})[wl] = detail
+    t["note"] = ("bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; FETCH doubled per MI355X_MICROARCH.md, gfx950), L2 <-> fabric "
+                 "including Infinity-Cache hits; per STEP by kernel class (k_scan = scan kernels + their second stage + stripe closing), "
+                 "step_bytes = all launches of a step")
+    json.dump(t, open(path, "w"), indent=1)
+    print(json.dumps({wl: out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

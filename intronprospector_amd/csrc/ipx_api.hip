@@ -123,7 +123,8 @@ struct ipx_handle {
     bool have_genome = false;
     std::vector<std::string> gnames;
     std::vector<int64_t> glen;
-    DevBuf d_twobit, d_mask, d_seq_len, d_seq_word2, d_seq_wordm, d_seq_of_rank;
+    DevBuf d_twobit, d_mask, d_seq_len, d_seq_word2, d_seq_wordm, d_seq_of_rank, d_rank_seq;
+    std::vector<uint64_t> g_word2, g_wordm;      // first twobit / mask word of each genome sequence
     // records
     DevBuf items_a, items_b, pays, cnts, dig_a, dig_b;
     bool opt_combine = true;       // IPX_OPT_COMBINE: the short-read scan may merge equal-key records of a tile
@@ -338,6 +339,12 @@ int rebuild_ranks(ipx_handle *h) {
                 if (h->gnames[g] == nm) { sor[r] = (int32_t)g; break; }
         }
         if ((rc = upload(h, h->d_seq_of_rank, sor.data(), sor.size() * sizeof(int32_t)))) return rc;
+        std::vector<RankSeq> rs(sor.size());
+        for (size_t r = 0; r < sor.size(); ++r) {
+            const int32_t g = sor[r];
+            rs[r] = g < 0 ? RankSeq{-1, 0, 0, 0} : RankSeq{(long long)h->glen[g], h->g_word2[g], h->g_wordm[g], 0};
+        }
+        if ((rc = upload(h, h->d_rank_seq, rs.data(), rs.size() * sizeof(RankSeq)))) return rc;
     }
     HIPCHK(ipx_stream_wait(h->stream));
     return IPX_OK;
@@ -406,6 +413,7 @@ GenomeDev genome_dev(const ipx_handle *h) {
         g.twobit = h->d_twobit.as<uint32_t>(); g.mask = h->d_mask.as<uint32_t>();
         g.seq_len = h->d_seq_len.as<int64_t>(); g.seq_word2 = h->d_seq_word2.as<uint64_t>();
         g.seq_wordm = h->d_seq_wordm.as<uint64_t>(); g.seq_of_rank = h->d_seq_of_rank.as<int32_t>();
+        g.rank_seq = h->d_rank_seq.as<RankSeq>();
     }
     return g;
 }
@@ -469,7 +477,7 @@ int ipx_destroy(ipx_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->pending.active = false;
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
-                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
+                      &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->d_rank_seq, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
                       &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer})
         release(*b);
@@ -541,6 +549,8 @@ int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names
     if ((rc = upload(h, h->d_seq_len, h->glen.data(), n_seqs * sizeof(int64_t)))) return rc;
     if ((rc = upload(h, h->d_seq_word2, w2.data(), n_seqs * sizeof(uint64_t)))) return rc;
     if ((rc = upload(h, h->d_seq_wordm, wm.data(), n_seqs * sizeof(uint64_t)))) return rc;
+    h->g_word2 = w2;
+    h->g_wordm = wm;
     HIPCHK(ipx_stream_wait(h->stream));      // caller memory is borrowed until return
     return rebuild_ranks(h);
 }

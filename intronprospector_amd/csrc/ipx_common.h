@@ -68,6 +68,12 @@ struct KeyLayout {
 struct DigitSpec {
     uint32_t lo1, w1, lo2, w2;
 };
+// what a key rank's genome sequence is, in one 32-byte load
+struct RankSeq {
+    long long len;                    // sequence length; -1: the genome has no sequence of that name
+    unsigned long long word2, wordm;  // first twobit / mask word of the sequence
+    unsigned long long pad;
+};
 struct GenomeDev {
     const uint32_t *twobit;      // 16 bases per word, all sequences concatenated (word aligned per sequence)
     const uint32_t *mask;        // 32 bases per word
@@ -75,6 +81,7 @@ struct GenomeDev {
     const uint64_t *seq_word2;   // first twobit word of the sequence
     const uint64_t *seq_wordm;   // first mask word of the sequence
     const int32_t *seq_of_rank;  // per key rank: genome sequence index, -1 = missing, -2 = no genome
+    const RankSeq *rank_seq;     // the same per key rank, resolved (one dependent load less per look-up)
 };
 struct ScanParams {
     uint32_t min_anchor_length, max_anchor_indel_size, min_intron_length, max_intron_length;
@@ -210,15 +217,15 @@ __device__ __forceinline__ bool ipx_canon4(uint32_t d0, uint32_t d1, uint32_t a0
 // 0x200 = a fetch ran past the end of the sequence (genome.cc:68-70)
 __device__ __forceinline__ uint32_t ipx_motif_of(const GenomeDev &g, int32_t skip_missing, uint32_t rank,
                                                  uint32_t start, uint32_t end) {
-    const int32_t seq = g.seq_of_rank ? g.seq_of_rank[rank] : -2;
-    if (seq == -2) return 0u;                                   // no genome: splice_sites == ""
-    if (seq < 0) return skip_missing ? 0u : 0x100u;
-    const int64_t L = g.seq_len[seq];
+    if (!g.seq_of_rank) return 0u;                              // no genome: splice_sites == ""
+    const RankSeq rs = g.rank_seq[rank];
+    if (rs.len < 0) return skip_missing ? 0u : 0x100u;
+    const int64_t L = rs.len;
     const int64_t s = (int64_t)(int32_t)start, e = (int64_t)(int32_t)end;   // Genome::fetch takes int
     // faidx clamps to the sequence; a fetch that returns fewer than 2 bases throws.
     // acceptor [e-2,e) is fetched first (see oracle/ipxo_core.c get_splice_sites)
     if (e - 2 < 0 || e > L || s < 0 || s + 2 > L) return 0x200u;
-    const uint64_t w2 = g.seq_word2[seq], wm = g.seq_wordm[seq];
+    const uint64_t w2 = rs.word2, wm = rs.wordm;
     const uint32_t d0 = ipx_base2(g, w2, s), d1 = ipx_base2(g, w2, s + 1);
     const uint32_t a0 = ipx_base2(g, w2, e - 2), a1 = ipx_base2(g, w2, e - 1);
     const uint32_t non = ipx_maskbit(g, wm, s) | ipx_maskbit(g, wm, s + 1) | ipx_maskbit(g, wm, e - 2) |

@@ -25,6 +25,8 @@
 // prefix-summed once (k_count_heads + scan), so no per-record id array is stored.
 #include "ipx_common.h"
 #include "ipx_reduce.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -140,6 +142,26 @@ __global__ __launch_bounds__(256) void k_motif(uint32_t n_j, GenomeDev g, int32_
     jmotif[j] = m;
 }
 
+// Without a genome k_reduce<0> writes the segment descriptors itself (see there); what is left of k_write_heads
+// is setting the rows it accumulates into to the identity: one pass over J + B words instead of over the records.
+__global__ __launch_bounds__(256) void k_init_rows(uint32_t n_j, uint32_t n_b, unsigned long long *__restrict__ first,
+                                                   unsigned long long *__restrict__ creator,
+                                                   unsigned long long *__restrict__ counts, uint32_t *__restrict__ amin,
+                                                   uint32_t *__restrict__ amax, uint32_t *__restrict__ bin_count,
+                                                   uint32_t *__restrict__ totals) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 == 0) {
+        totals[0] = n_j; totals[1] = n_b;          // nothing is dropped without a genome
+        totals[2] = 0; totals[3] = 0; totals[4] = 0; totals[5] = ~0u; totals[6] = ~0u;
+    }
+    for (uint64_t j = t0; j < n_j; j += stride) {
+        first[j] = ~0ull; creator[j] = ~0ull;
+        amin[j] = ~0u; amax[j] = 0u;
+        counts[3 * j] = 0; counts[3 * j + 1] = 0; counts[3 * j + 2] = 0;
+    }
+    for (uint64_t b = t0; b < n_b; b += stride) bin_count[b] = 0;
+}
+
 // ---- wave-segmented reductions -------------------------------------------------
 // seg ids are non-decreasing over the lanes; the result is valid at head lanes.
 __device__ __forceinline__ uint32_t seg_last_lane(uint64_t heads, uint32_t lane) {
@@ -235,6 +257,13 @@ __device__ __forceinline__ JAcc bcast_acc(const JAcc &x, int src) {
     return r;
 }
 
+// where k_reduce<0> leaves the segment descriptors when no genome is set (jrank == nullptr: k_write_heads did it)
+struct HeadOut {
+    uint32_t *jrank, *jstart, *jend, *jfirstbin, *jmotif;
+    uint16_t *hist_value;
+    KeyLayout kl;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
                                                 const uint4 *__restrict__ pays,
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
                                                 unsigned long long *__restrict__ creator,
                                                 unsigned long long *__restrict__ counts,
                                                 uint32_t *__restrict__ amin, uint32_t *__restrict__ amax,
-                                                uint32_t *__restrict__ bin_count, Counters *counters) {
+                                                uint32_t *__restrict__ bin_count, Counters *counters, HeadOut ho) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_le = ~0ull >> (63 - lane);
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -274,6 +303,15 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
         const uint32_t bid = nb + (uint32_t)__popcll(mb & lane_le) - 1;
         nj += (uint32_t)__popcll(mj);
         nb += (uint32_t)__popcll(mb);
+        if (MODE == 0 && ho.jrank && h.head_b) {
+            // segment descriptors (k_write_heads' job when a genome needs them before this kernel)
+            const KeyParts k = unpack_key(h.it, ho.kl);
+            ho.hist_value[bid] = (uint16_t)k.off16;
+            if (h.head_j) {
+                ho.jrank[jid] = k.rank; ho.jstart[jid] = k.start; ho.jend[jid] = k.end; ho.jfirstbin[jid] = bid;
+                ho.jmotif[jid] = 0;
+            }
+        }
         const int n_ok = __popcll(ok_mask);                 // valid lanes are 0..n_ok-1
         last_item = make_uint4(__shfl(h.it.x, n_ok - 1), __shfl(h.it.y, n_ok - 1), __shfl(h.it.z, n_ok - 1), 0);
         last_index = base + r * 64 + (uint64_t)(n_ok - 1);
@@ -628,9 +666,20 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     const uint32_t identity = genome.seq_of_rank == nullptr ? 1u : 0u;
     // ... and the bins' offsets and counts are written where the table has them (no k_emit_bins)
     uint32_t *bin_count = identity ? rb.out_hist_count : rb.bin_count;
-    hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
-                       rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, rb.totals,
-                       identity ? rb.jmotif : nullptr, J, B, identity ? rb.out_hist_value : nullptr);
+    // IPX_FUSE_HEADS=0: k_write_heads in every mode (tests run both)
+    const char *fuse_e = getenv("IPX_FUSE_HEADS");
+    const bool fuse_heads = identity && !(fuse_e && fuse_e[0] == '0');
+    HeadOut ho{};
+    if (fuse_heads) {
+        const uint64_t cells = (uint64_t)J + B;
+        hipLaunchKernelGGL(k_init_rows, dim3((uint32_t)std::min<uint64_t>(ipx_div_up(cells ? cells : 1, 1024), 4096)), dim3(256), 0, s, J, B,
+                           rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, rb.totals);
+        ho = HeadOut{rb.jrank, rb.jstart, rb.jend, rb.jfirstbin, rb.jmotif, rb.out_hist_value, kl};
+    } else {
+        hipLaunchKernelGGL(k_write_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, kl, rb.chunk_j, rb.chunk_b, rb.jrank, rb.jstart, rb.jend,
+                           rb.jfirstbin, rb.bin_off, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, rb.totals,
+                           identity ? rb.jmotif : nullptr, J, B, identity ? rb.out_hist_value : nullptr);
+    }
     ipx_prof_mark(s, IPXK_WRITE_HEADS);
     if (!identity) {
         hipLaunchKernelGGL(k_motif, grid1d(J, 256), dim3(256), 0, s, J, genome, skip_missing, rb.jrank,
@@ -643,14 +692,14 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     if (!filter_active) {
         ipx_prof_pre(s, IPXK_PHASE_B);
         hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
-                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters);
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters, ho);
         ipx_prof_mark(s, IPXK_PHASE_B);
     } else {
         hipLaunchKernelGGL(k_reduce<1>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
-                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
         ipx_prof_mark(s, IPXK_PHASE_A);
         hipLaunchKernelGGL(k_reduce<2>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
-                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters);
+                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
         ipx_prof_mark(s, IPXK_PHASE_B);
     }
     hipLaunchKernelGGL(k_finish_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.first, rb.creator,

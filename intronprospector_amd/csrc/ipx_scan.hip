@@ -1379,6 +1379,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             for (uint32_t r = 0; r < CR; ++r) {
                 const uint32_t k = r * BT + t;
                 pass_r[r] = true;
+                if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
                 if (p.combine == 2u && k < total) {
                     const uint4 it = pool_item[k];
                     const uint32_t px = pool_pay[k].x;
@@ -1389,6 +1390,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             }
 #pragma unroll
             for (uint32_t r = 0; r < CR; ++r) {
+                if (r * BT >= total) continue;
                 const uint32_t k = r * BT + t;
                 bool live = k < total;
                 uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);

@@ -201,33 +201,8 @@ void AlnReader::parse_bam_header() {
     }
 }
 
-bool AlnReader::read_bam(AlnRecord &rec) {
-    if (pending_advance_) {                  // the previous record was parsed where it lay: release it now
-        bgzf_->advance(pending_advance_);
-        pending_advance_ = 0;
-    }
-    const uint8_t *b = nullptr;
-    uint32_t block = 0;
-    const uint8_t *pk = nullptr;
-    if (bgzf_ && bgzf_->peek(4, &pk)) {
-        block = le32(pk);
-        if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
-        if (bgzf_->peek(4 + (size_t)block, &pk)) {       // the whole record lies in this block: no copy
-            b = pk + 4;
-            pending_advance_ = 4 + (size_t)block;
-        }
-    }
-    if (!b) {
-        uint8_t w[4];
-        const size_t r = read_some(w, 4);
-        if (r == 0) return false;
-        if (r != 4) throw std::runtime_error("Error reader BAM record: " + path_);
-        block = le32(w);
-        if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
-        buf_.resize(block);
-        read_exact(buf_.data(), block, "record");
-        b = buf_.data();
-    }
+void parse_bam_record(const uint8_t *b, uint32_t block, const std::string &path_, BamFields &rec) {
+    if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
     rec.tid = (int32_t)le32(b);
     rec.pos = (int32_t)le32(b + 4);
     const uint32_t l_read_name = b[8];
@@ -236,7 +211,7 @@ bool AlnReader::read_bam(AlnRecord &rec) {
     const uint32_t l_seq = le32(b + 16);
     size_t off = 32;
     if (off + l_read_name > block) throw std::runtime_error("Error reader BAM record: " + path_);
-    if (keep_qname_) rec.qname.assign((const char *)b + off, l_read_name ? l_read_name - 1 : 0);
+    rec.l_read_name = l_read_name;
     off += l_read_name;
     if (off + 4ull * n_cigar > block) throw std::runtime_error("Error reader BAM record: " + path_);
     rec.cig = b + off;                       // little-endian words, as the device wants them
@@ -244,10 +219,7 @@ bool AlnReader::read_bam(AlnRecord &rec) {
     off += 4ull * n_cigar;
     off += (l_seq + 1) / 2 + l_seq;
     if (off > block) throw std::runtime_error("Error reader BAM record: " + path_);
-    if (keep_raw_) {
-        rec.raw.assign((const char *)b, block);
-        rec.aux_off = (uint32_t)off;
-    }
+    rec.aux_off = (uint32_t)off;
     // aux fields
     rec.xs = 0;
     rec.nh = 0;
@@ -299,9 +271,52 @@ bool AlnReader::read_bam(AlnRecord &rec) {
         off = p + sz;
     }
     // long CIGARs live in the CG tag behind a "<l_seq>S<ref_len>N" placeholder (SAM spec 4.2.2)
-    if (cg && n_cigar == 2 && (rec.cigar_word(0) & 0xf) == 4 && (rec.cigar_word(0) >> 4) == l_seq && (rec.cigar_word(1) & 0xf) == 3) {
+    if (cg && n_cigar == 2 && (le32(rec.cig) & 0xf) == 4 && (le32(rec.cig) >> 4) == l_seq && (le32(rec.cig + 4) & 0xf) == 3) {
         rec.cig = cg;
         rec.n_cig = cg_n;
+    }
+}
+
+bool AlnReader::read_bam(AlnRecord &rec) {
+    if (pending_advance_) {                  // the previous record was parsed where it lay: release it now
+        bgzf_->advance(pending_advance_);
+        pending_advance_ = 0;
+    }
+    const uint8_t *b = nullptr;
+    uint32_t block = 0;
+    const uint8_t *pk = nullptr;
+    if (bgzf_ && bgzf_->peek(4, &pk)) {
+        block = le32(pk);
+        if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
+        if (bgzf_->peek(4 + (size_t)block, &pk)) {       // the whole record lies in this block: no copy
+            b = pk + 4;
+            pending_advance_ = 4 + (size_t)block;
+        }
+    }
+    if (!b) {
+        uint8_t w[4];
+        const size_t r = read_some(w, 4);
+        if (r == 0) return false;
+        if (r != 4) throw std::runtime_error("Error reader BAM record: " + path_);
+        block = le32(w);
+        if (block < 32) throw std::runtime_error("Error reader BAM record: " + path_);
+        buf_.resize(block);
+        read_exact(buf_.data(), block, "record");
+        b = buf_.data();
+    }
+    BamFields f;
+    parse_bam_record(b, block, path_, f);
+    rec.tid = f.tid;
+    rec.pos = f.pos;
+    rec.flag = f.flag;
+    rec.xs = f.xs;
+    rec.nh = f.nh;
+    rec.cig = f.cig;
+    rec.n_cig = f.n_cig;
+    if (keep_qname_) rec.qname.assign((const char *)b + 32, f.l_read_name ? f.l_read_name - 1 : 0);
+    if (keep_raw_) {
+        rec.raw.assign((const char *)b, block);
+        rec.aux_off = f.aux_off;
     }
     return true;
 }

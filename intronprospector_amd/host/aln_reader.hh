@@ -38,6 +38,18 @@ struct AlnRecord {
     uint32_t aux_off = 0;
 };
 
+// What the hot path reads of one BAM record (the record body b[0 .. block), i.e. without its block_size word).
+struct BamFields {
+    int32_t tid = -1, pos = 0;
+    uint16_t flag = 0;
+    uint8_t xs = 0, nh = 0;
+    const uint8_t *cig = nullptr;        // CIGAR words (the CG tag's for a long CIGAR), unaligned
+    uint32_t n_cig = 0;
+    uint32_t l_read_name = 0, aux_off = 0;
+};
+// throws std::runtime_error("Error reader BAM record: <path>") on a malformed record
+void parse_bam_record(const uint8_t *b, uint32_t block, const std::string &path, BamFields &f);
+
 class AlnReader {
 public:
     explicit AlnReader(const std::string &path);     // throws std::runtime_error
@@ -55,6 +67,10 @@ public:
     // SAM: the header lines; BAM: everything between the magic and the first record (l_text ... refs)
     const std::string &raw_header() const { return raw_header_; }
     unsigned decode_threads() const { return bgzf_ ? bgzf_->threads() : 1; }
+    // the BGZF block source of a BAM file (null for SAM text, pipes, plain-gzip BAM): host/bam_feeder.cc parses
+    // whole blocks on several threads instead of calling read() per record
+    BgzfReader *bgzf() { return bam_ ? bgzf_.get() : nullptr; }
+    const std::string &path() const { return path_; }
     // false at end of input; throws std::runtime_error on a malformed record
     bool read(AlnRecord &rec);
 

@@ -32,7 +32,7 @@ bool BgzfReader::is_bgzf(const std::string &path) {
 
 // CPUs this process may use: the hardware threads, cut to the cgroup's CPU quota when there is one (a
 // container on a 256-thread host may own 16)
-static unsigned usable_cpus() {
+unsigned BgzfReader::usable_cpus() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                  // cgroup v2: "<quota|max> <period>"
         char q[32];
@@ -73,6 +73,9 @@ BgzfReader::BgzfReader(const std::string &path, unsigned n_threads) : path_(path
         n_threads = v > 0 ? (unsigned)v : default_threads();
     }
     n_threads = std::min(n_threads, 64u);
+    // four blocks per thread: 3 MB of inflated data for twelve threads, which stays in the CPU's caches between the
+    // worker that fills a block and the thread that reads it (4096 slots, tried so that the pool could run ahead of
+    // a consumer busy opening its GPU, made the consumer a third slower: every block came from DRAM)
     ring_.resize((size_t)n_threads * 4);
     for (unsigned i = 0; i < n_threads; ++i) workers_.emplace_back(&BgzfReader::worker, this);
 }
@@ -200,6 +203,21 @@ void BgzfReader::advance(size_t n) {
         }
         cur_valid_ = false;
         can_produce_.notify_all();
+    }
+}
+
+bool BgzfReader::next_block(std::vector<uint8_t> &out) {
+    for (;;) {
+        const uint8_t *p;
+        if (!peek(0, &p)) return false;             // waits for the next block; false: end of file
+        Slot &s = ring_[next_consume_ % ring_.size()];
+        const size_t left = s.out.size() - cur_off_;
+        if (left == 0) { advance(0); continue; }    // an empty block (the end-of-file marker)
+        if (cur_off_ == 0) out.swap(s.out);
+        else out.assign(s.out.begin() + (long)cur_off_, s.out.end());
+        cur_off_ = s.out.size();                    // (after the swap: whatever `out` held; the slot is released next)
+        advance(0);
+        return true;
     }
 }
 

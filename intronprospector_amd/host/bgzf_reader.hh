@@ -26,6 +26,8 @@ public:
     explicit BgzfReader(const std::string &path, unsigned n_threads = 0);
     // three quarters of the CPUs this process may use (cgroup quota respected), at most 12 (measured)
     static unsigned default_threads();
+    // CPUs this process may use (hardware threads, cut to the cgroup's quota)
+    static unsigned usable_cpus();
     ~BgzfReader();
     BgzfReader(const BgzfReader &) = delete;
     BgzfReader &operator=(const BgzfReader &) = delete;
@@ -37,6 +39,10 @@ public:
     // blocks or the input has ended); the pointer stays valid until advance(), which consumes the bytes.
     bool peek(size_t n, const uint8_t **p);
     void advance(size_t n);
+    // Whole blocks for a consumer that parses them elsewhere (host/bam_feeder.cc): the rest of the current block
+    // (after read / advance consumed its head) or the whole next one is swapped into `out`, whose old storage the
+    // ring reuses.  false at the end of the input.
+    bool next_block(std::vector<uint8_t> &out);
     unsigned threads() const { return (unsigned)workers_.size(); }
     uint64_t compressed_bytes() const { return compressed_bytes_; }
 

@@ -1,6 +1,7 @@
 // host_check.cc -- small driver that exposes the host-side pieces (alignment decoding,
 // ordering, confidence, writers) to the CPU-only tests; it never touches the GPU.
 //   ipx_host_check dump-aln FILE
+//   ipx_host_check dump-feed FILE [by-target|all [CAP_ALN [CAP_WORDS]]]   the same through host/bam_feeder.cc
 //       one line per alignment: tid pos flag xs nh n_cigar w0,w1,...
 //   ipx_host_check print-table PREFIX MIN_CONF < table.txt
 //       table.txt: one junction per line in std::map order,
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "aln_reader.hh"
+#include "bam_feeder.hh"
 #include "gz_ostream.hh"
 #include "junctions.hh"
 #include "pass_through.hh"
@@ -42,6 +44,55 @@ static int dump_aln(const char *path) {
         printf("%d\t%lld\t%u\t%u\t%u\t%zu\t", r.tid, (long long)r.pos, r.flag, r.xs, r.nh, (size_t)r.n_cig);
         for (size_t k = 0; k < r.n_cig; ++k) printf(k ? ",%u" : "%u", r.cigar_word(k));
         printf("\n");
+    }
+    return 0;
+}
+
+// the same listing through the block-parallel feeder (host/bam_feeder.cc): target by target like the sorted-mode
+// loop when by_target, else everything at once; small batches so that spans get cut in every possible place
+static int dump_feed(const char *path, bool by_target, size_t cap_aln, size_t cap_words) {
+    AlnReader rd(path);
+    for (size_t i = 0; i < rd.target_names().size(); ++i)
+        printf("@SQ\t%s\t%lld\n", rd.target_names()[i].c_str(), (long long)rd.target_lengths()[i]);
+    if (!rd.bgzf()) { fprintf(stderr, "not a BGZF-compressed BAM file\n"); return 1; }
+    std::vector<int32_t> canon(rd.target_names().size());
+    for (size_t i = 0; i < canon.size(); ++i) canon[i] = (int32_t)i;
+    BamFeeder feeder(*rd.bgzf(), path, canon);
+    std::vector<int32_t> tid(cap_aln), pos(cap_aln);
+    std::vector<uint16_t> flag(cap_aln);
+    std::vector<uint8_t> xs(cap_aln), nh(cap_aln);
+    std::vector<uint32_t> off(cap_aln), nc(cap_aln), cigar(cap_words);
+    size_t n = 0, nw = 0;
+    auto flush = [&]() {
+        feeder.wait_all();
+        for (size_t i = 0; i < n; ++i) {
+            printf("%d\t%lld\t%u\t%u\t%u\t%zu\t", tid[i], (long long)pos[i], flag[i], xs[i], nh[i], (size_t)nc[i]);
+            for (size_t k = 0; k < nc[i]; ++k) printf(k ? ",%u" : "%u", cigar[off[i] + k]);
+            printf("\n");
+        }
+        n = nw = 0;
+    };
+    const int n_targets = (int)canon.size();
+    for (int t = by_target ? 0 : -1; t < (by_target ? n_targets : 0); ++t) {
+        for (;;) {
+            BamFeeder::Span sp;
+            int32_t other = 0;
+            const BamFeeder::Status st = feeder.next_span(by_target ? t : BamFeeder::ANY_TARGET, cap_aln - n, cap_words - nw, sp, &other);
+            if (st == BamFeeder::SPAN) {
+                const BamFeeder::Dest d{tid.data(), pos.data(), flag.data(), xs.data(), nh.data(), off.data(), nc.data(), cigar.data()};
+                const size_t rn = sp.n_records, rw = sp.n_words;
+                feeder.dispatch(std::move(sp), d, n, nw);
+                n += rn;
+                nw += rw;
+            } else if (st == BamFeeder::FULL) {
+                if (n == 0) { cap_words *= 4; cigar.resize(cap_words); }
+                flush();
+            } else {
+                break;
+            }
+        }
+        flush();
+        if (by_target) printf("#target %d done\n", t);
     }
     return 0;
 }
@@ -213,6 +264,9 @@ static int bench_inflate(const char *path, const char *threads) {
 int main(int argc, char **argv) {
     try {
         if (argc == 3 && std::string(argv[1]) == "dump-aln") return dump_aln(argv[2]);
+        if (argc >= 3 && std::string(argv[1]) == "dump-feed")
+            return dump_feed(argv[2], argc > 3 && std::string(argv[3]) == "by-target", argc > 4 ? strtoull(argv[4], nullptr, 10) : 1000,
+                             argc > 5 ? strtoull(argv[5], nullptr, 10) : 6000);
         if (argc == 4 && std::string(argv[1]) == "print-table") return print_table(argv[2], strtof(argv[3], nullptr));
         if (argc >= 4 && std::string(argv[1]) == "copy-aln") return copy_aln(argc, argv);
         if (argc == 4 && std::string(argv[1]) == "make-bam") return make_bam(strtoull(argv[2], nullptr, 10), argv[3]);

@@ -6,6 +6,7 @@
 // --pass-through, --set-XS/TS-strand-tag and --debug-trace are host work over the
 // device's record list (host/junctions_extractor.cc, host/pass_through.cc).
 #include <getopt.h>
+#include <future>
 
 #include <algorithm>
 #include <cerrno>
@@ -216,8 +217,7 @@ struct OutputFiles {
 };
 
 // src/intronProspector.cc:330-351
-static void output_junctions(JunctionsExtractor &extractor, float min_confidence_score, OutputFiles &output) {
-    JunctionVector juncs = extractor.get_junctions();
+static void write_junctions(JunctionVector &juncs, float min_confidence_score, OutputFiles &output) {
     if (output.junction_bed_fh) {
         juncs.sort_by_anchors();
         print_anchor_bed(juncs, min_confidence_score, *output.junction_bed_fh);
@@ -228,6 +228,11 @@ static void output_junctions(JunctionsExtractor &extractor, float min_confidence
         if (output.intron_bed6_fh) print_intron_bed(juncs, min_confidence_score, 6, *output.intron_bed6_fh);
         if (output.intron_call_fh) print_intron_call_tsv(juncs, min_confidence_score, *output.intron_call_fh);
     }
+}
+
+static void output_junctions(JunctionsExtractor &extractor, float min_confidence_score, OutputFiles &output) {
+    JunctionVector juncs = extractor.get_junctions();
+    write_junctions(juncs, min_confidence_score, output);
 }
 
 static void extract_junctions(const Options &o) {
@@ -258,11 +263,21 @@ static void extract_junctions(const Options &o) {
     } else {                                            // :356-371
         extractor.open(o.bam_files[0]);
         if (!o.bam_pass_through.empty()) extractor.open_pass_through(o.bam_pass_through);
+        // a target's rows are written (sorted, formatted: 0.3 s for 200 000 junctions) on a thread of their own
+        // while the next target's alignments are read; rows leave in target order, one writer at a time, and a
+        // writer still running when a later target throws finishes first (the future's destructor waits): what the
+        // reference had flushed for the earlier targets stays written
+        std::future<void> writer;
         for (int target_index = 0; target_index < extractor.get_num_targets(); target_index++) {
             extractor.identify_junctions_for_target(target_index);
-            output_junctions(extractor, o.min_confidence_score, output);
+            std::shared_ptr<JunctionVector> juncs(new JunctionVector(extractor.get_junctions()));
             extractor.clear();
+            if (writer.valid()) writer.get();
+            const float conf = o.min_confidence_score;
+            OutputFiles *out = &output;
+            writer = std::async(std::launch::async, [juncs, conf, out] { write_junctions(*juncs, conf, *out); });
         }
+        if (writer.valid()) writer.get();
         extractor.copy_unaligned_reads();
         extractor.close();
     }

@@ -1,6 +1,7 @@
 // junctions_extractor.cc -- see junctions_extractor.hh.
 #include "junctions_extractor.hh"
 #include <chrono>
+#include <sys/stat.h>
 #include <cstdlib>
 #include <cstring>
 
@@ -17,6 +18,11 @@ JunctionFilter junction_filter_parse(const std::string &spec) {
     if (spec == "canon") return CANON_SJ_FILTER;
     throw std::invalid_argument("invalid splice junction filter '" + spec + "', expected 'all' or 'canon'");
 }
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct ScopeTimer { double &acc; double t0; ~ScopeTimer() { acc += now_s() - t0; } };
 
 JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_anchor_indel_size,
                                        uint32_t min_intron_length, uint32_t max_intron_length,
@@ -39,25 +45,38 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
     p.scope = IPX_SCOPE_TARGET;
     p.skip_missing_targets = skip_missing_targets ? 1 : 0;
     p.device = devices.empty() ? device : devices[0];
+    t_born_ = now_s();
+    { const char *e = getenv("IPX_TIMELINE"); timeline_ = e && e[0] == '1'; }
+    // the trace and the strand tags walk one device's record list in input order
+    if (devices.size() > 1 && (trace_fh_ || set_xs_ || set_ts_))
+        throw std::invalid_argument("--devices with more than one GPU cannot be combined with --debug-trace or the strand-tag options");
+    params_ = p;
+    devices_ = devices;
+    init_thread_ = std::thread([this] {
+        try {
+            init_device();
+        } catch (...) {
+            init_error_ = std::current_exception();
+        }
+    });
+}
+
+void JunctionsExtractor::init_device() {
     int rc;
-    if (devices.size() > 1) {
-        // the trace and the strand tags walk one device's record list in input order
-        if (trace_fh_ || set_xs_ || set_ts_)
-            throw std::invalid_argument("--devices with more than one GPU cannot be combined with --debug-trace or the strand-tag options");
-        std::vector<int32_t> devs(devices.begin(), devices.end());
-        rc = ipx_group_create(&p, (uint32_t)devs.size(), devs.data(), &g_);
+    if (devices_.size() > 1) {
+        std::vector<int32_t> devs(devices_.begin(), devices_.end());
+        rc = ipx_group_create(&params_, (uint32_t)devs.size(), devs.data(), &g_);
     } else {
-        rc = ipx_create(&p, &h_);
+        rc = ipx_create(&params_, &h_);
     }
     if (rc == IPX_ENODEVICE)
         throw std::runtime_error("no MI355X (gfx950) device available: this build has no CPU path");
-    if (rc != IPX_OK) throw std::runtime_error(g_ || devices.size() > 1 ? "ipx_group_create failed" : "ipx_create failed");
+    if (rc != IPX_OK) throw std::runtime_error(devices_.size() > 1 ? "ipx_group_create failed" : "ipx_create failed");
     // the trace and the strand tags walk the single junction records (export_records)
     if (trace_fh_ || set_xs_ || set_ts_) {
         rc = ipx_set_option(h_, IPX_OPT_COMBINE, 0);
         if (rc != IPX_OK) throw_last_error(rc);
     }
-    { const char *e = getenv("IPX_TIMELINE"); timeline_ = e && e[0] == '1'; }
     if (genome_) {
         const size_t n = genome_->n_seqs();
         std::vector<const char *> names(n);
@@ -73,25 +92,46 @@ JunctionsExtractor::JunctionsExtractor(uint32_t min_anchor_length, uint32_t max_
                 : ipx_set_genome_2bit(h_, (uint32_t)n, names.data(), lens.data(), two.data(), msk.data());
         if (rc != IPX_OK) throw_last_error(rc);
     }
+    t_create_ = now_s() - t_born_;
+}
+
+// before anything that touches the device: the opening thread has finished, the target list is the current one
+void JunctionsExtractor::ensure_device() {
+    if (init_thread_.joinable()) init_thread_.join();
+    if (init_error_) {
+        std::exception_ptr e = init_error_;
+        std::rethrow_exception(e);                  // (kept: every later call fails the same way)
+    }
+    if (targets_dirty_) {
+        targets_dirty_ = false;
+        std::vector<const char *> names(targets_.size());
+        for (size_t i = 0; i < targets_.size(); ++i) names[i] = targets_[i].c_str();
+        int rc = g_ ? ipx_group_set_targets(g_, (uint32_t)names.size(), names.data(), nullptr)
+                    : ipx_set_targets(h_, (uint32_t)names.size(), names.data(), nullptr);
+        if (rc != IPX_OK) throw_last_error(rc);
+    }
 }
 
 JunctionsExtractor::~JunctionsExtractor() {
     if (timeline_)
         std::cerr << "{\"ipx_timeline\": {\"alignments\": " << next_read_index_ << ", \"pushes\": " << n_push_
                   << ", \"read_s\": " << t_read_ << ", \"queue_s\": " << t_queue_ << ", \"push_wait_s\": " << t_push_
-                  << ", \"finalize_s\": " << t_finalize_ << ", \"table_to_host_rows_s\": " << t_table_ << "}}" << std::endl;
+                  << ", \"finalize_s\": " << t_finalize_ << ", \"table_to_host_rows_s\": " << t_table_
+                  << ", \"device_create_s\": " << t_create_ << ", \"pinned_alloc_s\": " << t_alloc_
+                  << ", \"open_s\": " << t_open_ << ", \"identify_s\": " << t_identify_ << ", \"get_junctions_s\": " << t_getj_
+                  << ", \"close_s\": " << t_close_ << ", \"extractor_lifetime_s\": " << now_s() - t_born_ << "}}" << std::endl;
+    if (init_thread_.joinable()) init_thread_.join();
     if (h_) ipx_destroy(h_);
     if (g_) ipx_group_destroy(g_);
     for (HostBatch &b : batch_)
         if (b.mem) ipx_host_free(b.mem);
 }
 
-static double now_s() {
-    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 // (re)allocate a batch's pinned arrays; the batch must be empty
 void JunctionsExtractor::size_batch(HostBatch &b, size_t cap_aln, size_t cap_words) {
+    ensure_device();             // pinned memory comes from the HIP runtime: without a device say so, not "out of memory"
+    struct AllocTimer { double &acc; double t0; ~AllocTimer() { acc += now_s() - t0; } } alloc_timer{t_alloc_, now_s()};
     if (b.mem) ipx_host_free(b.mem);
     b = HostBatch();
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -124,6 +164,7 @@ void JunctionsExtractor::throw_last_error(int status) {
 
 // junctions_extractor.cc:571-586 (save_targets :564-568 appends)
 void JunctionsExtractor::open(const std::string &bam) {
+    ScopeTimer scope_timer{t_open_, now_s()};
     bam_ = bam;
     reader_.reset(new AlnReader(bam));
     reader_->keep_qname(trace_fh_ != nullptr);        // read names only go into the --debug-trace rows
@@ -134,11 +175,7 @@ void JunctionsExtractor::open(const std::string &bam) {
         targets_.push_back(nm);
         canon_tid_.push_back(first);
     }
-    std::vector<const char *> names(targets_.size());
-    for (size_t i = 0; i < targets_.size(); ++i) names[i] = targets_[i].c_str();
-    int rc = g_ ? ipx_group_set_targets(g_, (uint32_t)names.size(), names.data(), nullptr)
-                : ipx_set_targets(h_, (uint32_t)names.size(), names.data(), nullptr);
-    if (rc != IPX_OK) throw_last_error(rc);
+    targets_dirty_ = true;          // handed to the device by ensure_device()
     if (trace_fh_)          // junctions_extractor.cc:579-584 (nine names over ten columns, as there)
         *trace_fh_ << "chrom" << "\t" << "intron_start" << "\t" << "intron_end" << "\t" << "qname" << "\t" << "flag" << "\t"
                    << "strand" << "\t" << "splice_sites" << "\t" << "anchor_start" << "\t" << "anchor_end" << std::endl;
@@ -159,10 +196,12 @@ void JunctionsExtractor::copy_unaligned_reads() {
 
 // junctions_extractor.cc:605-617
 void JunctionsExtractor::close() {
+    ScopeTimer scope_timer{t_close_, now_s()};
     if (pass_through_) {
         pass_through_->close();
         pass_through_.reset();
     }
+    feeder_.reset();
     reader_.reset();
     previous_target_ = -1;
     aln_pending_ = false;
@@ -220,7 +259,13 @@ void JunctionsExtractor::process_alignment(const AlnRecord &aln) {
 
 void JunctionsExtractor::flush_batch() {
     HostBatch &hb = batch_[cur_];
+    if (feeder_) {                               // the parsers are still filling the batch
+        const double tw = timeline_ ? now_s() : 0.0;
+        feeder_->wait_all();
+        if (timeline_) t_queue_ += now_s() - tw;
+    }
     if (hb.n == 0) return;
+    ensure_device();
     ipx_batch b{};
     b.n_alignments = hb.n;
     b.n_cigar_words = hb.nw;
@@ -239,9 +284,71 @@ void JunctionsExtractor::flush_batch() {
     if (rc != IPX_OK) throw_last_error(rc);
 }
 
+bool JunctionsExtractor::use_feeder() {
+    if (feeder_) return true;
+    if (!reader_ || !reader_->bgzf() || pass_through_ || trace_fh_ || aln_pending_) return false;
+    // IPX_PARSE_THREADS=N (N >= 1) asks for it, 0 forbids it.  Unasked, it is used where the parsers do not take
+    // CPUs away from the inflate pool: on the GPU box's 16-CPU share (12 inflate threads + the loop) a 10 M-record
+    // BAM took 1.3-1.4 s without it and 1.3-1.5 s with it -- inflating is 7 of the 8 CPU-seconds either way
+    const char *e = getenv("IPX_PARSE_THREADS");
+    const long asked = e ? atol(e) : -1;
+    if (asked == 0) return false;
+    if (asked < 0 && BgzfReader::usable_cpus() < 24) return false;
+    feeder_.reset(new BamFeeder(*reader_->bgzf(), reader_->path(), canon_tid_));
+    return true;
+}
+
+bool JunctionsExtractor::feed_target(int32_t target_index, int32_t *other_tid) {
+    for (;;) {
+        HostBatch *b = &batch_[cur_];
+        if (b->cap_aln == 0) {
+            // a large file gets full-size arrays at once (pinned allocations cost milliseconds each); a small one
+            // starts small and grows, see below
+            struct stat st;
+            const bool large = stat(reader_->path().c_str(), &st) == 0 && (uint64_t)st.st_size > (64ull << 20);
+            size_batch(*b, large ? BATCH_ALIGNMENTS : (size_t)1 << 16, large ? BATCH_ALIGNMENTS * 8 : (size_t)1 << 19);
+        }
+        BamFeeder::Span sp;
+        const double t0 = timeline_ ? now_s() : 0.0;
+        const BamFeeder::Status st = feeder_->next_span(target_index, b->cap_aln - b->n, b->cap_words - b->nw, sp, other_tid);
+        if (timeline_) t_read_ += now_s() - t0;
+        if (st == BamFeeder::SPAN) {
+            const BamFeeder::Dest d{b->tid, b->pos, b->flag, b->xs, b->nh, b->off, b->nc, b->cigar};
+            const uint64_t n = sp.n_records, w = sp.n_words;
+            feeder_->dispatch(std::move(sp), d, b->n, b->nw);
+            b->n += n;
+            b->nw += w;
+            table_valid_ = false;
+        } else if (st == BamFeeder::FULL) {
+            const size_t had_aln = b->cap_aln, had_words = b->cap_words;
+            const bool empty = b->n == 0;
+            flush_batch();
+            b = &batch_[cur_];
+            // the next set of arrays: eight times the last one up to BATCH_ALIGNMENTS; a record that did not even
+            // fit an empty batch needs more room for its CIGAR
+            const size_t want_aln = std::max(b->cap_aln, std::min<size_t>(BATCH_ALIGNMENTS, had_aln * 8));
+            const size_t want_words = std::max(std::max(b->cap_words, want_aln * 8), empty ? had_words * 4 : (size_t)0);
+            if (want_aln > b->cap_aln || want_words > b->cap_words) size_batch(*b, want_aln, want_words);
+        } else {
+            return st == BamFeeder::BOUNDARY;
+        }
+    }
+}
+
 // identify_junctions_for_target (junctions_extractor.cc:656-664) with
 // process_target_alignment (:637-652)
 void JunctionsExtractor::identify_junctions_for_target(int target_index) {
+    ScopeTimer scope_timer{t_identify_, now_s()};
+    if (use_feeder()) {
+        int32_t other = -1;
+        if (feed_target(target_index, &other) && other >= 0 && other < previous_target_) {
+            finalize_table();
+            throw std::runtime_error("BAM appears to not be coordinate sorted");
+        }
+        previous_target_ = target_index;
+        finalize_table();
+        return;
+    }
     while (read_align()) {
         if (aln_buf_.tid != target_index) {
             if (aln_buf_.tid >= 0 && aln_buf_.tid < previous_target_) {
@@ -269,6 +376,13 @@ void JunctionsExtractor::identify_junctions_for_target(int target_index) {
 
 // identify_junctions_for_bam (junctions_extractor.cc:678-683)
 void JunctionsExtractor::identify_junctions_for_bam() {
+    ScopeTimer scope_timer{t_identify_, now_s()};
+    if (use_feeder()) {
+        int32_t other = -1;
+        (void)feed_target(BamFeeder::ANY_TARGET, &other);
+        finalize_table();
+        return;
+    }
     while (read_align()) process_alignment(aln_buf_);
     finalize_table();
 }
@@ -283,6 +397,7 @@ static char complement(char c) {
 
 void JunctionsExtractor::finalize_table() {
     flush_batch();
+    ensure_device();
     ipx_table t;
     const double t0 = timeline_ ? now_s() : 0.0;
     int rc = g_ ? ipx_group_finalize(g_, &t) : ipx_finalize(h_, IPX_MEM_HOST, &t);
@@ -370,6 +485,7 @@ void JunctionsExtractor::finalize_table() {
 // A table that is finalized again after more alignments only adds the lines of the new alignments.
 // the handle's records in the order the reference's loop met them
 std::vector<ipx_record> JunctionsExtractor::export_records() {
+    ensure_device();
     uint64_t n = 0;
     int rc = ipx_records_pending(h_, &n);
     if (rc != IPX_OK) throw_last_error(rc);
@@ -441,6 +557,7 @@ void JunctionsExtractor::write_trace(const ipx_table &t, const std::vector<ipx_r
 
 // JunctionTable::get_junctions, junctions.hh:232-238
 JunctionVector JunctionsExtractor::get_junctions() {
+    ScopeTimer scope_timer{t_getj_, now_s()};
     if (!table_valid_) finalize_table();
     return table_;
 }
@@ -451,6 +568,7 @@ void JunctionsExtractor::clear() {
     ijunc_ += (uint32_t)table_.size();
     table_.clear();
     table_valid_ = true;          // an empty table is the table of no records
+    ensure_device();
     int rc = g_ ? ipx_group_clear(g_) : ipx_clear(h_);
     if (rc != IPX_OK) throw_last_error(rc);
     trace_qname_.clear();

@@ -20,10 +20,13 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
+#include <exception>
 #include <vector>
 
 #include "../../include/ipx.h"
 #include "aln_reader.hh"
+#include "bam_feeder.hh"
 #include "genome.hh"
 #include "junctions.hh"
 #include "pass_through.hh"
@@ -69,6 +72,16 @@ private:
     // spread over the group's GPUs by read index, the junction records meet by key range over RCCL
     ipx_handle *h_ = nullptr;
     ipx_group *g_ = nullptr;
+    // The device is opened on a thread of its own while the caller already opens the input (its BGZF blocks
+    // inflate in the meantime): HIP start-up, handle, genome upload take 0.2 s.  Everything that touches
+    // h_ / g_ goes through ensure_device() first, which also hands over the target list open() collected.
+    ipx_params params_{};
+    std::vector<int> devices_;
+    std::thread init_thread_;
+    std::exception_ptr init_error_;
+    bool targets_dirty_ = false;
+    void init_device();
+    void ensure_device();
     Genome *genome_;
     bool skip_missing_targets_;
     std::ostream *warn_;
@@ -96,10 +109,18 @@ private:
     };
     HostBatch batch_[2];
     int cur_ = 0;
+    // BAM input with nothing that needs the records one by one (pass-through, trace): blocks are split on this
+    // thread and parsed straight into the batches by a pool (host/bam_feeder.hh); IPX_PARSE_THREADS=0 keeps
+    // the record-by-record loop
+    std::unique_ptr<BamFeeder> feeder_;
+    bool use_feeder();
+    // records of target_index (BamFeeder::ANY_TARGET: all) from the feeder into the batches;
+    // returns false at the end of the input, true at a record of another target (*other_tid)
+    bool feed_target(int32_t target_index, int32_t *other_tid);
     void size_batch(HostBatch &b, size_t cap_aln, size_t cap_words);
     // IPX_TIMELINE=1: where the wall time of the command goes (stderr, one JSON line at destruction)
     bool timeline_ = false;
-    double t_read_ = 0, t_queue_ = 0, t_push_ = 0, t_finalize_ = 0, t_table_ = 0;
+    double t_read_ = 0, t_queue_ = 0, t_push_ = 0, t_finalize_ = 0, t_table_ = 0, t_create_ = 0, t_alloc_ = 0, t_born_ = 0, t_identify_ = 0, t_close_ = 0, t_getj_ = 0, t_open_ = 0;
     uint64_t n_push_ = 0;
     uint32_t tick_ = 0;
     // finalized table of the records pushed since the last clear()

@@ -2,7 +2,9 @@
 # End-to-end wall time of the command line on a 10 M-record BAM (coordinate-sorted synthetic short reads),
 # with the host's own phase sums (IPX_TIMELINE=1): profiles/r02_cli_timeline.jsonl
 #   read_s       time in AlnReader::read on the parsing thread (BGZF inflate runs on a thread pool beside it)
-#   queue_s      process_alignment: the record into the pinned SoA batch
+#   queue_s      process_alignment: the record into the pinned SoA batch; with the block-parallel feeder (BAM input,
+#                no pass-through / trace): the time the loop waited for the parse workers before a push
+#                (read_s is then the splitting thread: record lengths, waiting for inflated blocks)
 #   push_wait_s  time the loop spent inside ipx_push_batch_async (completing the previous batch, queuing this one)
 #   finalize_s   ipx_finalize calls (sort + reduce + table to pinned host memory)
 set -e

@@ -202,6 +202,15 @@ def test_cli_against_the_oracle_on_odd_sam_files(cli, oracle_cli, tmp_path, opts
     subprocess.run([cli] + opts + ["--intron-calls=" + tsv, "--debug-trace=" + trace, bam], check=True)
     assert open(tsv, "rb").read() == outs["exp"][2]["introns.tsv"]
     assert open(trace, "rb").read() == outs["exp"][2]["trace.tsv"]
+    # without the trace the BAM goes through the block-parallel feeder (host/bam_feeder.cc); with IPX_PARSE_THREADS=0
+    # through the record-by-record loop: the same bytes either way
+    for k, env in enumerate(({"IPX_PARSE_THREADS": "2"}, {"IPX_PARSE_THREADS": "0"}, {"IPX_PARSE_THREADS": "3", "IPX_DECODE_THREADS": "2"})):
+        o = {name: str(tmp_path / ("feed%d.%s" % (k, name))) for name in ("juncs.bed", "introns.bed", "introns.bed6", "introns.tsv")}
+        subprocess.run([cli] + opts + ["--junction-bed=" + o["juncs.bed"], "--intron-bed=" + o["introns.bed"],
+                                       "--intron-bed6=" + o["introns.bed6"], "--intron-calls=" + o["introns.tsv"], bam],
+                       check=True, env=dict(os.environ, **env))
+        for name, path in o.items():
+            assert open(path, "rb").read() == outs["exp"][2][name], (env, name)
     # get_read_category's logic_error (src/junctions_extractor.cc:73-74): same message, same exit status, and
     # what the earlier targets had already written stays written
     _fuzz_sam(sam, seed=7, sorted_by_target=True, mapped_unmapped=True)
@@ -211,6 +220,30 @@ def test_cli_against_the_oracle_on_odd_sam_files(cli, oracle_cli, tmp_path, opts
         r = subprocess.run([exe] + opts + ["--intron-calls=" + tsv, sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         res.append((r.returncode, r.stderr, open(tsv, "rb").read()))
     assert res[0] == res[1] and res[0][0] == 1 and b"should never look at" in res[0][1]
+    bamio.sam_to_bam(sam, bam)                     # the same through the feeder
+    tsv = str(tmp_path / "bam.err.tsv")
+    r = subprocess.run([cli] + opts + ["--intron-calls=" + tsv, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, IPX_PARSE_THREADS="2"))
+    assert (r.returncode, r.stderr, open(tsv, "rb").read()) == res[1]
+
+
+def test_cli_block_parallel_bam_feeder(cli, tmp_path):
+    """host/bam_feeder.cc on a BAM of a few hundred BGZF blocks (records straddle most block ends), sorted and
+    --unsorted, several GPUs' worth of members included: byte-identical with the record-by-record reader"""
+    import hashlib
+    bam = str(tmp_path / "many.bam")
+    subprocess.run([os.path.join(os.path.dirname(cli), "ipx_host_check"), "make-bam", "300000", bam], check=True)
+    digests = set()
+    for mode in ([], ["--unsorted"]):
+        for env, extra in (({"IPX_PARSE_THREADS": "0"}, []), ({"IPX_PARSE_THREADS": "4"}, []), ({"IPX_PARSE_THREADS": "2"}, ["--devices=0,0"])):
+            tsv, bed = str(tmp_path / "o.tsv"), str(tmp_path / "o.bed")
+            subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed] + mode + extra + [bam], check=True,
+                           env=dict(os.environ, **env))
+            h = hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest()
+            digests.add((bool(mode), h))
+            assert os.path.getsize(tsv) > 10000
+    assert len(digests) == 2, digests                   # one digest per mode, whatever the reader
+
 
 
 def test_cli_gzip_outputs(cli, golden, tmp_path):

@@ -142,6 +142,43 @@ def test_bgzf_blocks_inflate_in_parallel_in_file_order(host_check, tmp_path):
     assert r.returncode == 1 and b"Error reader BAM record" in r.stderr
 
 
+def test_block_parallel_bam_feeder_equals_the_record_reader(host_check, tmp_path):
+    """host/bam_feeder.cc: blocks split on one thread, parsed on a pool -- the same records in the same order as
+    AlnReader::read, whole-file and target by target, with batches so small that spans are cut everywhere, on odd
+    records (every aux type, `*` CIGARs, unplaced reads), on a few hundred blocks whose ends cut through records,
+    and on a long CIGAR kept in the CG tag"""
+    from tests.test_gpu_cli import _fuzz_sam
+
+    def dump(args):
+        r = subprocess.run([host_check] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        return [l for l in r.stdout.splitlines() if not l.startswith(b"#")]
+    sam, bam = str(tmp_path / "odd.sam"), str(tmp_path / "odd.bam")
+    for seed in (3, 7):
+        _fuzz_sam(sam, seed=seed, sorted_by_target=True, mapped_unmapped=seed == 7)
+        bamio.sam_to_bam(sam, bam)
+        ref = dump(["dump-aln", bam])
+        assert dump(["dump-feed", bam, "all"]) == ref
+        assert dump(["dump-feed", bam, "all", "37", "150"]) == ref
+        by_target = dump(["dump-feed", bam, "by-target", "50", "300"])        # stops where the sorted-mode loop stops
+        assert 3000 < len(by_target) <= len(ref) and by_target == ref[:len(by_target)]
+    many = str(tmp_path / "many.bam")
+    subprocess.run([host_check, "make-bam", "120000", many], check=True)
+    ref = dump(["dump-aln", many])
+    for args in (["all"], ["all", "777", "2500"], ["by-target", "100000", "800000"]):
+        assert dump(["dump-feed", many] + args) == ref, args
+    long_sam = tmp_path / "long.sam"
+    cig = "".join("%dM%dN" % (3 + (i % 5), 100 + i) for i in range(40)) + "7M"
+    seq = "A" * (sum(3 + (i % 5) for i in range(40)) + 7)
+    long_sam.write_text("@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:100000000\n" +
+                        "".join("r%d\t0\tchr1\t%d\t60\t%s\t*\t0\t0\t%s\t*\tNH:i:1\n" % (k, 101 + k, cig if k % 2 else "20M100N20M", seq if k % 2 else "A" * 40)
+                                for k in range(50)))
+    long_bam = str(tmp_path / "long.bam")
+    bamio.sam_to_bam(str(long_sam), long_bam, long_cigar_threshold=10)       # odd records: the CG:B:I path
+    ref = dump(["dump-aln", long_bam])
+    assert dump(["dump-feed", long_bam, "all", "7", "90"]) == ref and len(ref) == 51
+
+
 def test_pass_through_writer_and_strand_tag_edits(host_check, golden, tmp_path):
     """host/pass_through.cc (SURVEY 8f-2): SAM and BAM pass-through keep every record as it came;
     update_strand_tag semantics (src/junctions_extractor.cc:98-111): the first tag of that name goes,

@@ -370,6 +370,11 @@ def main():
                     help="N=1 only: run the N>1 code path (process group of one rank) to exercise the RCCL calls")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: libraries that print there on their own (RCCL's version banner when the
+    # first communicator is made) are sent to stderr until the line goes out
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -551,10 +556,12 @@ def main():
             except Exception as e:                   # the headline line must still come out
                 configs[k2] = {"error": repr(e)[:300]}
         out["configs"] = configs
-    if rank == 0:
-        print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -86,6 +86,21 @@ def test_config_L_long_reads():
     ora.close()
 
 
+def test_config_L_2M_long_reads():
+    """BASELINE.json's long-read configuration at its full size: 2 M ONT-style alignments, 1.65 G CIGAR operations,
+    40 M junction records, the whole table against the oracle (a minute of generating, seconds of oracle)"""
+    from intronprospector_amd import synth
+    batch, names, _ = synth.long_reads(2_000_000, seed=synth.SEED_L)
+    p = {"max_anchor_indel_size": 36}
+    t1 = _run(batch, names, n_push=2, **p)
+    _check_properties(t1, 2_000_000)
+    assert len(t1["intron_start"]) > 400_000 and int(t1["n_records"]) > 40_000_000
+    ora = Oracle(targets=names, **p)
+    ora.process(batch)
+    helpers.compare_tables(t1, ora.table())
+    ora.close()
+
+
 def test_config_G_genome_strand_inference(tmp_path):
     """10 M short reads over a 160 Mb synthetic genome (2-bit on the device), --sj-filter=canon."""
     from intronprospector_amd import synth, _lib as L

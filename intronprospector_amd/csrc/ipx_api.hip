@@ -697,6 +697,9 @@ static int push_complete(ipx_handle *h) {
         bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
         // second stage: alignments the short-CIGAR kernel only listed (more than 8 ops, overflowing tiles)
         const uint32_t n_defer = pp.use_ops ? 0u : tail4[0];
+        if (getenv("IPX_DEBUG_PLAN"))
+            fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away, %u alignments left to the second stage\n",
+                    (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged, n_defer);
         if (n_defer && !layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             HIPCHK(ipx_launch_scan_rest(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
                                         h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),

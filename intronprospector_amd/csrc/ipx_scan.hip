@@ -1140,6 +1140,204 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         if (p.combine)
             for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
         __syncthreads();
+        // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one; see the
+        // comments inside.  final_pass: survivors go to the record arrays; else they close ranks inside the pool so
+        // that the tile can go on filling it (recombine: the pool may hold records an earlier pass made of several).
+        auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
+            // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
+            // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
+            // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
+            // exchange) then handles one record per key and tile.  What a group keeps is what the reduce would
+            // have made of its members anyway: the smallest order64 (with that record's strand), the smallest
+            // anchor start, the largest anchor end, the reads per category (item.w, IPX_CNT_*; it is 0 in the
+            // pool).  The first record of a key to claim a table slot OWNS the group, the others add themselves
+            // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
+            // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
+            // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
+            // active junction filter: only records that pass it may stand for others (ScanParams::combine); the
+            // others stay what they are, one read each.  The genome look-ups of all rounds go out together.
+            // fold the wave's copies of its first live key with shuffles, then claim / find the key's owner in the
+            // table and add this record (or the wave's fold) to the owner's pool entry
+            auto fold_and_insert = [&](uint32_t k, const uint4 &it, uint32_t cat, unsigned long long ord, uint32_t lo,
+                                       uint32_t hi, uint32_t cw, bool live) {
+                bool dead = false;
+                const unsigned long long lm = ipx_ballot(live);
+                if (lm) {
+                    const int f = __ffsll(lm) - 1;
+                    const uint32_t fx = __builtin_amdgcn_readlane(it.x, f), fy = __builtin_amdgcn_readlane(it.y, f),
+                                   fz = __builtin_amdgcn_readlane(it.z, f);
+                    const bool same = live && it.x == fx && it.y == fy && it.z == fz;
+                    const unsigned long long sm = ipx_ballot(same);
+                    if (__popcll(sm) >= 8) {
+                        unsigned long long o = same ? ord : ~0ull;
+                        uint32_t l = same ? lo : ~0u, h = same ? hi : 0u;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) {
+                            const unsigned long long o2 = __shfl_xor(o, d);
+                            const uint32_t l2 = __shfl_xor(l, d), h2 = __shfl_xor(h, d);
+                            o = o2 < o ? o2 : o;
+                            l = l2 < l ? l2 : l;
+                            h = h2 > h ? h2 : h;
+                        }
+                        uint32_t c0, c1, c2;
+                        if (!recombine) {                                           // one read per lane: count lanes
+                            c0 = (uint32_t)__popcll(ipx_ballot(same && cat == 0u));
+                            c1 = (uint32_t)__popcll(ipx_ballot(same && cat == 1u));
+                            c2 = (uint32_t)__popcll(ipx_ballot(same && cat == 2u));
+                        } else {                                                    // lanes may stand for several reads
+                            uint32_t w01 = same ? ((cw & IPX_CNT_MASK) | (((cw >> IPX_CNT_BITS) & IPX_CNT_MASK) << 16)) : 0u;
+                            uint32_t w2 = same ? (cw >> (2 * IPX_CNT_BITS)) : 0u;
+#pragma unroll
+                            for (int d = 32; d >= 1; d >>= 1) { w01 += __shfl_xor(w01, d); w2 += __shfl_xor(w2, d); }
+                            c0 = w01 & 0xffffu; c1 = w01 >> 16; c2 = w2;
+                        }
+                        if ((int)lane == f) {
+                            ord = o; lo = l; hi = h;
+                            cw = c0 | (c1 << IPX_CNT_BITS) | (c2 << (2 * IPX_CNT_BITS));
+                        } else if (same) {
+                            live = false;
+                            dead = true;
+                        }
+                    }
+                }
+                if (live) {
+                    uint32_t hs = it.x * 0x9E3779B1u;
+                    hs ^= it.y * 0x85EBCA77u;
+                    hs ^= it.z * 0xC2B2AE3Du;
+                    hs ^= hs >> 15;
+                    hs = (hs * 0x2C1B3C6Du) >> (32 - HT_BITS);
+                    uint32_t owner = k;
+                    for (;;) {
+                        const uint32_t o = atomicCAS(&ht[hs], HT_EMPTY, k);
+                        if (o == HT_EMPTY) break;                                   // the slot is mine: I own the key
+                        const uint4 ko = pool_item[o];
+                        if (ko.x == it.x && ko.y == it.y && ko.z == it.z) { owner = o; break; }
+                        hs = (hs + 1u) & (HT - 1u);
+                    }
+                    atomicAdd(&pool_item[owner].w, cw);
+                    atomicMin(reinterpret_cast<unsigned long long *>(&pool_pay[owner]), ord);
+                    atomicMin(&pool_pay[owner].z, lo);
+                    atomicMax(&pool_pay[owner].w, hi);
+                    dead = owner != k;
+                }
+                if (dead) pool_item[k].w = REC_DEAD;       // nobody adds to a record that owns nothing
+            };
+            uint4 it_s[CR];
+            unsigned long long ord_s[CR];
+            uint32_t lo_s[CR], hi_s[CR], cw_s[CR], cat_s[CR];
+            bool live_s[CR];
+            bool pass_r[CR];
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                pass_r[r] = true;
+                if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
+                if (p.combine == 2u && k < total) {
+                    const uint4 it = pool_item[k];
+                    const uint32_t px = pool_pay[k].x;
+                    const KeyParts kp = unpack_key(it, p.key);
+                    const uint32_t m = ipx_motif_of(p.genome, p.skip_missing, kp.rank, kp.start, kp.end);
+                    pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
+                }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                if (r * BT >= total) continue;
+                const uint32_t k = r * BT + t;
+                bool live = k < total;
+                uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);
+                if (live) { it = pool_item[k]; py = pool_pay[k]; }
+                const uint32_t cat = py.x & 3u;
+                live = live && cat != 3u;
+                if (live && !pass_r[r]) {
+                    live = false;
+                    pool_item[k].w = IPX_CNT_ONE(cat);
+                }
+                unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
+                // a record that an earlier combine of this tile made of several brings their counts along
+                uint32_t lo = py.z, hi = py.w, cw = (recombine && it.w) ? it.w : IPX_CNT_ONE(cat);
+                if (recombine) {
+                    if (live) pool_item[k].w = 0;             // the owners' count words start from nothing again
+                    it_s[r] = it; lo_s[r] = lo; hi_s[r] = hi; cw_s[r] = cw; ord_s[r] = ord; live_s[r] = live; cat_s[r] = cat;
+                    continue;
+                }
+                fold_and_insert(k, it, cat, ord, lo, hi, cw, live);
+            }
+            if (recombine) {
+                __syncthreads();                               // every count word of the pool is zero now
+#pragma unroll
+                for (uint32_t r = 0; r < CR; ++r) {
+                    if (r * BT >= total) continue;
+                    fold_and_insert(r * BT + t, it_s[r], cat_s[r], ord_s[r], lo_s[r], hi_s[r], cw_s[r], live_s[r]);
+                }
+            }
+            __syncthreads();
+            // survivors close ranks: position = survivors before it in pool order
+            uint32_t pos_r[CR];
+            bool live_r[CR];
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                live_r[r] = k < total && pool_item[k].w != REC_DEAD;
+                const unsigned long long m = ipx_ballot(live_r[r]);
+                pos_r[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (lane == 0) live_n[r][wave] = (uint32_t)__popcll(m);
+            }
+            __syncthreads();
+            uint32_t n_out = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r)
+#pragma unroll
+                for (uint32_t w = 0; w < NW; ++w) {
+                    const uint32_t c = live_n[r][w];
+#pragma unroll
+                    for (uint32_t r2 = 0; r2 < CR; ++r2)
+                        if (r < r2 || (r == r2 && w < wave)) pos_r[r2] += c;
+                    n_out += c;
+                }
+            if (!final_pass) {
+                // make room: survivors move to the front of the pool, the table is emptied, the tile goes on
+                uint4 it2[CR], py2[CR];
+#pragma unroll
+                for (uint32_t r = 0; r < CR; ++r) {
+                    const uint32_t k = r * BT + t;
+                    if (live_r[r]) { it2[r] = pool_item[k]; py2[r] = pool_pay[k]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t r = 0; r < CR; ++r)
+                    if (live_r[r]) { pool_item[pos_r[r]] = it2[r]; pool_pay[pos_r[r]] = py2[r]; }
+                for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
+                if (t == 0) {
+                    pool_n = n_out;
+                    merged_acc += total - n_out;
+                }
+                __syncthreads();
+                return;
+            }
+            if (t == 0) {
+                tile_slot = n_out ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)n_out) : 0ull;
+                merged_acc += total - n_out;
+            }
+            __syncthreads();
+            const uint64_t slot = tile_slot;
+#pragma unroll
+            for (uint32_t r = 0; r < CR; ++r) {
+                const uint32_t k = r * BT + t;
+                const uint64_t idx = append_index(p, stripe, slot + pos_r[r]);
+                if (live_r[r] && idx < capacity) {
+                    uint4 it = pool_item[k];
+                    cnts[idx] = it.w;
+                    it.w = (uint32_t)idx;
+                    items[idx] = it;
+                    pays[idx] = pool_pay[k];
+                    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+                }
+            }
+        };
+        bool recombined = false;                 // (block-uniform) an early combine made room in this tile
         // Phase 1, every alignment of the tile: the plain spliced reads "aM nN bM" (two thirds of short-read data)
         // and "aM nN bM nN cM" (most of the rest) have closed forms -- one or two junctions, anchors a, b, c, no
         // counters.  Everything else is only LISTED here and walked in phase 2 by as few waves as it fills: a wave
@@ -1211,10 +1409,29 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     pool_pay[slot] = pay;
                 }
             }
+            // A tile of mostly two-junction reads emits more than the pool holds (S: 3 % of the tiles, a quarter of
+            // all records that left the scan uncombined through the second stage).  If the first half of the tile
+            // filled more than its share, fold what is there and go on in the room that makes.
+            if (r + 1 < RPT && p.combine) {
+                __syncthreads();
+                const uint32_t filled = pool_n;
+                if (2u * filled + 64u > POOL && filled <= POOL) {
+                    combine_pool(filled, false, false);
+                    recombined = true;
+                }
+            }
         }
         __syncthreads();
         // Phase 2: the listed alignments, 64 per wave
         const uint32_t n_walk = cx_n;
+        // (room for their records -- up to three from eight ops -- if the closed forms nearly filled the pool)
+        if (p.combine && n_walk) {
+            const uint32_t filled = pool_n;
+            if (filled + 3u * n_walk > POOL && filled <= POOL && filled > POOL / 2) {
+                combine_pool(filled, false, recombined);
+                recombined = true;
+            }
+        }
 #pragma unroll 1
         for (uint32_t k0 = wave * 64; k0 < n_walk; k0 += BT) {
             const bool mine = k0 + lane < n_walk;
@@ -1362,145 +1579,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 }
             }
         } else if (total <= POOL) {
-            // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
-            // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
-            // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
-            // exchange) then handles one record per key and tile.  What a group keeps is what the reduce would
-            // have made of its members anyway: the smallest order64 (with that record's strand), the smallest
-            // anchor start, the largest anchor end, the reads per category (item.w, IPX_CNT_*; it is 0 in the
-            // pool).  The first record of a key to claim a table slot OWNS the group, the others add themselves
-            // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
-            // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
-            // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
-            // active junction filter: only records that pass it may stand for others (ScanParams::combine); the
-            // others stay what they are, one read each.  The genome look-ups of all rounds go out together.
-            bool pass_r[CR];
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                const uint32_t k = r * BT + t;
-                pass_r[r] = true;
-                if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
-                if (p.combine == 2u && k < total) {
-                    const uint4 it = pool_item[k];
-                    const uint32_t px = pool_pay[k].x;
-                    const KeyParts kp = unpack_key(it, p.key);
-                    const uint32_t m = ipx_motif_of(p.genome, p.skip_missing, kp.rank, kp.start, kp.end);
-                    pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
-                }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                if (r * BT >= total) continue;
-                const uint32_t k = r * BT + t;
-                bool live = k < total;
-                uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);
-                if (live) { it = pool_item[k]; py = pool_pay[k]; }
-                const uint32_t cat = py.x & 3u;
-                live = live && cat != 3u;
-                if (live && !pass_r[r]) {
-                    live = false;
-                    pool_item[k].w = IPX_CNT_ONE(cat);
-                }
-                unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
-                uint32_t lo = py.z, hi = py.w, cw = IPX_CNT_ONE(cat);
-                bool dead = false;
-                const unsigned long long lm = ipx_ballot(live);
-                if (lm) {
-                    const int f = __ffsll(lm) - 1;
-                    const uint32_t fx = __builtin_amdgcn_readlane(it.x, f), fy = __builtin_amdgcn_readlane(it.y, f),
-                                   fz = __builtin_amdgcn_readlane(it.z, f);
-                    const bool same = live && it.x == fx && it.y == fy && it.z == fz;
-                    const unsigned long long sm = ipx_ballot(same);
-                    if (__popcll(sm) >= 8) {
-                        unsigned long long o = same ? ord : ~0ull;
-                        uint32_t l = same ? lo : ~0u, h = same ? hi : 0u;
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) {
-                            const unsigned long long o2 = __shfl_xor(o, d);
-                            const uint32_t l2 = __shfl_xor(l, d), h2 = __shfl_xor(h, d);
-                            o = o2 < o ? o2 : o;
-                            l = l2 < l ? l2 : l;
-                            h = h2 > h ? h2 : h;
-                        }
-                        const uint32_t c0 = (uint32_t)__popcll(ipx_ballot(same && cat == 0u)),
-                                       c1 = (uint32_t)__popcll(ipx_ballot(same && cat == 1u)),
-                                       c2 = (uint32_t)__popcll(ipx_ballot(same && cat == 2u));
-                        if ((int)lane == f) {
-                            ord = o; lo = l; hi = h;
-                            cw = c0 | (c1 << IPX_CNT_BITS) | (c2 << (2 * IPX_CNT_BITS));
-                        } else if (same) {
-                            live = false;
-                            dead = true;
-                        }
-                    }
-                }
-                if (live) {
-                    uint32_t hs = it.x * 0x9E3779B1u;
-                    hs ^= it.y * 0x85EBCA77u;
-                    hs ^= it.z * 0xC2B2AE3Du;
-                    hs ^= hs >> 15;
-                    hs = (hs * 0x2C1B3C6Du) >> (32 - HT_BITS);
-                    uint32_t owner = k;
-                    for (;;) {
-                        const uint32_t o = atomicCAS(&ht[hs], HT_EMPTY, k);
-                        if (o == HT_EMPTY) break;                                   // the slot is mine: I own the key
-                        const uint4 ko = pool_item[o];
-                        if (ko.x == it.x && ko.y == it.y && ko.z == it.z) { owner = o; break; }
-                        hs = (hs + 1u) & (HT - 1u);
-                    }
-                    atomicAdd(&pool_item[owner].w, cw);
-                    atomicMin(reinterpret_cast<unsigned long long *>(&pool_pay[owner]), ord);
-                    atomicMin(&pool_pay[owner].z, lo);
-                    atomicMax(&pool_pay[owner].w, hi);
-                    dead = owner != k;
-                }
-                if (dead) pool_item[k].w = REC_DEAD;       // nobody adds to a record that owns nothing
-            }
-            __syncthreads();
-            // survivors close ranks: position = survivors before it in pool order
-            uint32_t pos_r[CR];
-            bool live_r[CR];
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                const uint32_t k = r * BT + t;
-                live_r[r] = k < total && pool_item[k].w != REC_DEAD;
-                const unsigned long long m = ipx_ballot(live_r[r]);
-                pos_r[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (lane == 0) live_n[r][wave] = (uint32_t)__popcll(m);
-            }
-            __syncthreads();
-            uint32_t n_out = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r)
-#pragma unroll
-                for (uint32_t w = 0; w < NW; ++w) {
-                    const uint32_t c = live_n[r][w];
-#pragma unroll
-                    for (uint32_t r2 = 0; r2 < CR; ++r2)
-                        if (r < r2 || (r == r2 && w < wave)) pos_r[r2] += c;
-                    n_out += c;
-                }
-            if (t == 0) {
-                tile_slot = n_out ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)n_out) : 0ull;
-                merged_acc += total - n_out;
-            }
-            __syncthreads();
-            const uint64_t slot = tile_slot;
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                const uint32_t k = r * BT + t;
-                const uint64_t idx = append_index(p, stripe, slot + pos_r[r]);
-                if (live_r[r] && idx < capacity) {
-                    uint4 it = pool_item[k];
-                    cnts[idx] = it.w;
-                    it.w = (uint32_t)idx;
-                    items[idx] = it;
-                    pays[idx] = pool_pay[k];
-                    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
-                    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
-                    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
-                }
-            }
+            combine_pool(total, true, recombined);
         } else {
             // the pool overflowed: nothing of it is stored, the tile's alignments go to k_scan_rest (those
             // of more than 8 ops are on its list already)

@@ -578,3 +578,47 @@ def test_combiner_on_and_off_give_the_same_table(monkeypatch):
         digests.append((h.hexdigest(), t["n_records"]))
     assert digests[0] == digests[1]
     assert n_rec[0] * 3 < n_rec[1] == digests[1][1]        # hot junctions: far fewer records leave the scan
+
+
+def _pileup(cigars, n, seed, n_pos=40, nh_mix=True):
+    """n alignments drawn from a few CIGARs at a few positions of one locus, coordinate-sorted: the pile-up of a
+    highly expressed gene, every tile full of copies of a handful of (junction, offset) pairs"""
+    rng = np.random.default_rng(seed)
+    words = [np.array(_cig(c), np.uint32) for c in cigars]
+    which = rng.integers(0, len(words), n)
+    pos = np.sort(rng.integers(50_000, 50_000 + n_pos, n)).astype(np.int32)
+    nc = np.array([len(words[w]) for w in which], np.uint32)
+    off = np.zeros(n, np.uint32)
+    off[1:] = np.cumsum(nc[:-1])
+    return {"tid": np.zeros(n, np.int32), "pos": pos,
+            "flag": rng.choice(np.array([0, 16, 99, 147, 256], np.uint16), n),
+            "xs": np.zeros(n, np.uint8), "nh": (rng.integers(0, 3, n) if nh_mix else np.ones(n)).astype(np.uint8),
+            "cigar_off": off, "n_cigar": nc, "cigar": np.concatenate([words[w] for w in which])}
+
+
+@pytest.mark.parametrize("cigars", [
+    ["30M100N20M200N50M"],                                        # two records per read: 1024 per tile before folding
+    ["30M100N20M200N50M", "30M100N20M200N25M300N25M", "10S20M100N20M200N15M300N20M150N25M"],   # walks with 3-4 records
+    ["50M500N50M", "30M100N20M200N50M", "2S28M100N20M200N50M", "30M100N10M1D9M200N50M"],
+])
+def test_pile_up_tiles_fold_before_they_overflow_the_pool(cigars, monkeypatch):
+    """k_scan_short's early combine: a tile whose records would not fit the LDS pool folds what it has and goes
+    on (round 1 sent such tiles to the slow second stage, uncombined); against the oracle, and against the
+    combiner switched off"""
+    monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")        # the short-CIGAR kernel whatever the mean CIGAR length
+    batch = _pileup(cigars, 40_000, seed=len(cigars))
+    p = {"min_anchor_length": 8, "max_anchor_indel_size": 3}
+    dev, ora, err = _run_both(batch, ["chr1"], p, n_push=1)
+    assert err is None
+    helpers.compare_tables(dev, ora)
+    ex = _extractor(targets=["chr1"], **p)
+    ex.push(batch)
+    folded = ex.records_pending()
+    ex.close()
+    # a few hundred keys, tens of thousands of records; reads of more than 8 ops (a third of the second case)
+    # go through the second stage, which does not fold
+    limit = dev["n_records"] * (0.6 if any(len(_cig(c)) > 8 for c in cigars) else 0.05)
+    assert folded < limit, (folded, dev["n_records"])
+    monkeypatch.setenv("IPX_COMBINE", "0")
+    dev0, _, _ = _run_both(batch, ["chr1"], p)
+    helpers.compare_tables(dev0, ora)

@@ -152,6 +152,7 @@ struct ipx_handle {
     float push_ms = 0.f, fin_ms = 0.f;
     bool fin_timing_pending = false;
     PendingPush pending;
+    uint32_t rest_hint = 0;        // alignments the last short-CIGAR scan left to its second stage
     // a read-back that was begun but not yet waited for (read_back_begin / read_back_end)
     uint32_t rb_seq = 0, rb_words = 0;
     bool rb_by_copy = false;
@@ -585,7 +586,7 @@ static int launch_scan_attempt(ipx_handle *h) {
         HIPCHK(ipx_launch_scan(h->stream, pp.sp, pp.db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
                                h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
                                h->n_records, pp.use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
-                               h->defer.as<uint32_t>()));
+                               h->defer.as<uint32_t>(), h->rest_hint));
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
     // [defer count, -, merged records (64 bit)]: IPX_CNT_DEFER and IPX_CNT_MERGED are neighbours
     const uint32_t *defer_n_dev = reinterpret_cast<const uint32_t *>(h->counters.as<char>() + IPX_CNT_DEFER);
@@ -684,8 +685,6 @@ static int push_complete(ipx_handle *h) {
     pp.active = false;
     (void)hipSetDevice(h->params.device);
     ProfScope prof_scope(&h->prof);
-    const ipx_batch &db = pp.db;
-    const ScanParams &sp = pp.sp;
     int rc;
     for (;;) {
         if ((rc = read_back_end(h, h->pin_small))) return rc;
@@ -694,22 +693,13 @@ static int push_complete(ipx_handle *h) {
         const uint32_t *tail4 = (const uint32_t *)h->pin_small + sizeof(Counters) / 4;
         const uint64_t merged = pp.use_ops ? 0ull : ((uint64_t)tail4[2] | ((uint64_t)tail4[3] << 32));
         const bool layout_bad = pp.use_ops && c->pad[0] != 0;
-        bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
-        // second stage: alignments the short-CIGAR kernel only listed (more than 8 ops, overflowing tiles)
+        const bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
         const uint32_t n_defer = pp.use_ops ? 0u : tail4[0];
         if (getenv("IPX_DEBUG_PLAN"))
             fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away, %u alignments left to the second stage\n",
                     (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged, n_defer);
-        if (n_defer && !layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
-            HIPCHK(ipx_launch_scan_rest(h->stream, sp, db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                        h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
-                                        c->n_records, pp.use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
-                                        h->defer.as<uint32_t>(), n_defer));
-            HIPCHK(hipEventRecord(h->ev[1], h->stream));
-            if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4))) return rc;
-            h->prof.collect();
-            stripes_bad = c->pad[1] != 0;
-        }
+        // (the second stage ran behind the first on the device, see ipx_launch_scan; the count sizes the next one's grid)
+        h->rest_hint = n_defer;
         if (!layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->err_word_host = c->err_word;

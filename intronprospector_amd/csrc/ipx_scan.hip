@@ -1814,7 +1814,7 @@ __global__ void k_close_finish(Counters *counters, uint64_t base, uint64_t capac
 hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
-                           unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer) {
+                           unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer, uint32_t rest_hint) {
     if (b.n_alignments == 0) return hipSuccess;
     // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
     // Which kernel: the short-CIGAR kernel walks at most 8 ops per alignment itself and hands longer ones to a
@@ -1893,32 +1893,20 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
     }
-    if (p.n_stripes) {
-        unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
-        hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);
-        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, cnts, digs);
-        hipLaunchKernelGGL(k_close_finish, dim3(1), dim3(64), 0, s, counters, p.base, capacity, close_cap);
+    if (short_reads) {
+        // Second stage, in the same breath: the alignments k_scan_short only listed (more than 8 ops, tiles whose
+        // records overflowed the pool) are walked op by op by k_scan_rest, which reads the list's length on the
+        // device and leaves at once if it is zero.  Its grid follows what the previous batch listed (rest_hint):
+        // round 1 had the host read the count back and launch it with a fitting grid -- a second read-back and a
+        // second closing of the stripes on every batch that listed anything (S: 35 us of a 0.74 ms step for 512
+        // alignments).  A batch that lists far more than its predecessor runs the stage on too small a grid
+        // (slower, not wrong) and corrects the hint for the next one.
+        const uint32_t rest_blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ipx_div_up((uint64_t)rest_hint * 2, 256), 32), 2048);
+        const AlnArrays aln{b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar, rank_of_tid,
+                            b.n_alignments, b.n_cigar_words, b.base_read_index};
+        hipLaunchKernelGGL(k_scan_rest, dim3(rest_blocks), dim3(256), 0, s, p, aln, b.cigar, defer, items, pays, cnts, digs, capacity,
+                           counters);
     }
-    ipx_prof_mark(s, IPXK_SCAN);
-    return hipGetLastError();
-}
-
-// Second stage of a short-CIGAR scan: the n_defer alignments the first stage listed in defer[] (the caller read
-// the count back with the launch's counters; most launches list none and never get here).
-hipError_t ipx_launch_scan_rest(hipStream_t s, ScanParams p, const ipx_batch &b, const uint32_t *rank_of_tid,
-                                uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs, uint64_t capacity, Counters *counters,
-                                uint64_t n_records_before, unsigned long long *close_ws, uint64_t close_cap,
-                                const uint32_t *defer, uint32_t n_defer) {
-    if (n_defer == 0) return hipSuccess;
-    static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(ipx_div_up(n_defer, 256), 2048);
-    p.base = n_records_before;
-    p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
-    const AlnArrays aln{b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar, rank_of_tid,
-                        b.n_alignments, b.n_cigar_words, b.base_read_index};
-    ipx_prof_pre(s, IPXK_SCAN);
-    hipLaunchKernelGGL(k_scan_rest, dim3(blocks), dim3(256), 0, s, p, aln, b.cigar, defer, items, pays, cnts, digs, capacity,
-                       counters);
     if (p.n_stripes) {
         unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
         hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);

@@ -608,20 +608,32 @@ __global__ __launch_bounds__(256) void k_rank_mark(uint32_t n, const uint4 *__re
     }
 }
 
+// set bits below each word in two levels: inside its group of 64 words (one wave: before[w]) and per group
+// (group_total[g], prefix-summed afterwards -- 64 times fewer elements than a scan over all words: one launch
+// for a bitmap of 2^25 bits instead of three passes over a million counts)
 __global__ __launch_bounds__(256) void k_rank_popc(uint32_t n_words, const uint32_t *__restrict__ bitmap,
-                                                   uint32_t *__restrict__ counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_words) counts[i] = (uint32_t)__popc(bitmap[i]);
+                                                   uint32_t *__restrict__ before, uint32_t *__restrict__ group_total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t c = i < n_words ? (uint32_t)__popc(bitmap[i]) : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += x;
+    }
+    if (i < n_words) before[i] = incl - c;
+    if (lane == 63 && (i >> 6) < ((n_words + 63u) >> 6)) group_total[i >> 6] = incl;
 }
 
 __global__ __launch_bounds__(256) void k_rank_lookup(uint32_t n, const uint4 *__restrict__ items, RankBits rb,
                                                      const uint32_t *__restrict__ bitmap,
-                                                     const uint32_t *__restrict__ before, uint32_t *__restrict__ ijunc) {
+                                                     const uint32_t *__restrict__ before,
+                                                     const uint32_t *__restrict__ group_before, uint32_t *__restrict__ ijunc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint4 it = items[i];
         const uint32_t k = squeeze_rank_key(it, rb);
-        ijunc[it.w] = before[k >> 5] + (uint32_t)__popc(bitmap[k >> 5] & ((1u << (k & 31u)) - 1u));
+        ijunc[it.w] = group_before[k >> 11] + before[k >> 5] + (uint32_t)__popc(bitmap[k >> 5] & ((1u << (k & 31u)) - 1u));
     }
 }
 
@@ -736,20 +748,22 @@ hipError_t ipx_launch_emit_ijunc(hipStream_t s, uint32_t n_valid, const uint4 *_
 
 size_t ipx_rank_bitmap_workspace_bytes(uint32_t bits) {
     const uint64_t words = bits > 5 ? (1ull << (bits - 5)) : 1ull;
-    return (size_t)((2 * words + ipx_div_up(words, 4096) + 2) * sizeof(uint32_t));
+    const uint64_t groups = ipx_div_up(words, 64);
+    return (size_t)((2 * words + groups + 64 + ipx_scan_sums_words(groups, 0)) * sizeof(uint32_t));
 }
 
 hipError_t ipx_launch_rank_by_bitmap(hipStream_t s, uint32_t n_valid, const uint4 *rank_items, const RankBits &rb,
                                      uint32_t *workspace, uint32_t *ijunc) {
     if (n_valid == 0) return hipSuccess;
     const uint32_t words = rb.bits > 5 ? (1u << (rb.bits - 5)) : 1u;
-    uint32_t *bitmap = workspace, *before = workspace + words, *sums = before + words;
+    const uint32_t groups = (words + 63u) / 64u;
+    uint32_t *bitmap = workspace, *before = workspace + words, *group_before = before + words, *sums = group_before + groups + 64;
     hipError_t e;
     if ((e = hipMemsetAsync(bitmap, 0, (size_t)words * sizeof(uint32_t), s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_rank_mark, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, rank_items, rb, bitmap);
-    hipLaunchKernelGGL(k_rank_popc, grid1d(words, 256), dim3(256), 0, s, words, bitmap, before);
-    if ((e = ipx_launch_scan_u32(s, before, before, words, sums, nullptr)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_rank_lookup, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, rank_items, rb, bitmap, before, ijunc);
+    hipLaunchKernelGGL(k_rank_popc, grid1d(words, 256), dim3(256), 0, s, words, bitmap, before, group_before);
+    if ((e = ipx_launch_scan_u32(s, group_before, group_before, groups, sums, nullptr)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rank_lookup, grid1d(n_valid, 256), dim3(256), 0, s, n_valid, rank_items, rb, bitmap, before, group_before, ijunc);
     ipx_prof_mark(s, IPXK_RANK_SORT);
     return hipGetLastError();
 }

@@ -19,8 +19,8 @@ CLASS = [
     (r"k_scan_short|k_scan_long|k_scan_rest|k_scan_ops|k_close_|k_cigar_tail", "k_scan"),
     (r"k_scatter", "k_scatter"), (r"k_hist", "k_hist"), (r"k_binscan", "k_binscan"),
     (r"k_reduce<1>", "k_reduce_a"), (r"k_reduce", "k_reduce"),
-    (r"k_count_heads", "k_count_heads"), (r"k_write_heads", "k_write_heads"),
-    (r"k_scan_sums|k_scan_top|k_scan_apply", "scan_u32"),
+    (r"k_count_heads", "k_count_heads"), (r"k_write_heads|k_init_rows", "k_write_heads"),
+    (r"k_scan_sums|k_scan_top|k_scan_apply|k_scan_small", "scan_u32"),
     (r"k_emit_|k_finish_|k_motif|k_bins|k_rank_|k_publish|k_set_counters|fillBuffer|copyBuffer", "small"),
 ]
 

@@ -284,7 +284,8 @@ int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n
  * (src/junctions_extractor.cc:451-457,471-477): the trace is the list of records that a
  * junction counted, i.e. those with IPX_RECORD_SEQ(order) >= the creator_order of their row
  * in the table.  dst is host memory with room for `capacity` records; *n_records receives
- * the number the handle holds (nothing is written if that exceeds capacity). */
+ * the number the handle holds (nothing is written if that exceeds capacity).  The records must not have been
+ * combined: set IPX_OPT_COMBINE to 0 before the first push (IPX_EINVAL otherwise). */
 typedef struct ipx_record {
     uint64_t order;          /* read_index << 30 | ordinal << 10 | read strand << 2 | read category */
     uint32_t target;         /* as in ipx_table.target */

@@ -622,3 +622,33 @@ def test_pile_up_tiles_fold_before_they_overflow_the_pool(cigars, monkeypatch):
     monkeypatch.setenv("IPX_COMBINE", "0")
     dev0, _, _ = _run_both(batch, ["chr1"], p)
     helpers.compare_tables(dev0, ora)
+
+
+def test_records_export_needs_the_combiner_off():
+    """ipx_records_export hands out single junction records: refused once records were combined, fine with
+    IPX_OPT_COMBINE 0 (what the command line sets for --debug-trace and the strand tags); the option cannot change
+    while records are pending"""
+    import ctypes as C
+    from intronprospector_amd import synth, _lib as L
+    batch = _pileup(["50M500N50M"], 5000, seed=9)
+
+    class Rec(C.Structure):
+        _fields_ = [("order", C.c_uint64), ("target", C.c_uint32), ("intron_start", C.c_uint32), ("intron_end", C.c_uint32),
+                    ("anchor_start", C.c_uint32), ("anchor_end", C.c_uint32), ("read_offset", C.c_uint32)]
+    for combine in (True, False):
+        ex = _extractor(targets=["chr1"], combine=combine)
+        ex.push(batch)
+        n = ex.records_pending()
+        recs = (Rec * max(n, 1))()
+        got = C.c_uint64(0)
+        rc = ex.lib.ipx_records_export(ex.h, recs, n, C.byref(got))
+        if combine:
+            assert rc == L.IPX_EINVAL and n < 500 and b"IPX_OPT_COMBINE" in ex.last_error().detail
+        else:
+            assert rc == 0 and got.value == n and n > 3000                  # secondary alignments are QC-rejected
+            reads = sorted(int(r.order) >> 30 for r in recs[:n])
+            assert len(set(reads)) == n                                       # one record per read here
+        assert ex.lib.ipx_set_option(ex.h, L.IPX_OPT_COMBINE, 1) == L.IPX_EINVAL      # records pending
+        ex.clear()
+        assert ex.lib.ipx_set_option(ex.h, L.IPX_OPT_COMBINE, 1) == 0
+        ex.close()

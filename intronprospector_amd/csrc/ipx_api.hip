@@ -660,6 +660,7 @@ static int push_begin(ipx_handle *h, const ipx_batch *b) {
     const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
     sp.combine = (h->opt_combine && combine_env) ? (filter_active ? 2u : 1u) : 0u;
     sp.skip_missing = h->params.skip_missing_targets;
+    sp.rank_is_tid = h->params.scope == IPX_SCOPE_TARGET ? 1u : 0u;
     if (filter_active) sp.genome = genome_dev(h);
 
     // state to return to if a scan has to be repeated

@@ -104,6 +104,9 @@ struct ScanParams {
     // because the reduce drops those that precede the junction's creator one by one
     uint32_t combine;
     int32_t skip_missing;
+    // the key rank of a tid is the tid itself (IPX_SCOPE_TARGET): the scan then skips the dependent load of
+    // rank_of_tid[tid], one round trip per tile of short reads
+    uint32_t rank_is_tid;
     GenomeDev genome;
 };
 constexpr uint32_t IPX_STRIPES = 8;

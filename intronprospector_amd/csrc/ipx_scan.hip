@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
                             const uint32_t rej = ((flag & F_SECONDARY) || (p.exclude_multi && nhc == 2)) ? 0x400u : 0u;
                             stage.pos[lane] = (uint32_t)a_pos[i];
                             stage.meta[lane] = strand | (read_category(flag, nhc) << 8) | rej;
-                            stage.rank[lane] = rank_of_tid[tid];
+                            stage.rank[lane] = p.rank_is_tid ? (uint32_t)tid : rank_of_tid[tid];
                             stage.off[lane] = off;
                         }
                     }
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n,
                             const uint32_t rej = ((flag & F_SECONDARY) || (p.exclude_multi && nhc == 2)) ? 0x400u : 0u;
                             stage.pos[lane] = (uint32_t)a_pos[i];
                             stage.meta[lane] = strand | (read_category(flag, nhc) << 8) | rej;
-                            stage.rank[lane] = rank_of_tid[tid];
+                            stage.rank[lane] = p.rank_is_tid ? (uint32_t)tid : rank_of_tid[tid];
                             stage.off[lane] = off;
                         }
                     }
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArra
                     nc = 0;
                 }
                 c.nhc = nh;
-                c.rank = a.rank_of_tid[tid];
+                c.rank = p.rank_is_tid ? (uint32_t)tid : a.rank_of_tid[tid];
                 c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
                                                             : (xs ? xs : (uint32_t)'.');
             }
@@ -1085,6 +1085,17 @@ __device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArra
 __device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
     return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c) + IPX_CNT_DEFER);
 }
+
+// -DIPX_SCAN_STATS: where a block's cycles go, tile phase by tile phase (s_memtime on thread 0; a few blocks print)
+#ifdef IPX_SCAN_STATS
+#define IPX_ST_DECL unsigned long long st_t0 = 0, st_ph[6] = {0, 0, 0, 0, 0, 0}; uint32_t st_tiles = 0
+#define IPX_ST_START st_t0 = __builtin_readcyclecounter()
+#define IPX_ST_LAP(k) do { const unsigned long long st_now = __builtin_readcyclecounter(); st_ph[k] += st_now - st_t0; st_t0 = st_now; } while (0)
+#else
+#define IPX_ST_DECL
+#define IPX_ST_START
+#define IPX_ST_LAP(k)
+#endif
 
 template <uint32_t RPT, uint32_t POOL, uint32_t BT>
 __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
@@ -1117,6 +1128,11 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     static_assert(HT * 3 >= POOL * 4 && POOL <= IPX_CNT_MASK, "combiner table / count word too small for the pool");
     __shared__ uint32_t ht[HT];
     __shared__ uint32_t live_n[CR][NW];
+    // Before the combiner needs its table the same words hold, for the first STASH alignments listed for the walk,
+    // what phase 1 already fetched of them (position, rank, strand / category / QC bit / CIGAR length, CIGAR offset,
+    // first four CIGAR words): phase 2 then starts from LDS instead of repeating phase 1's two dependent round trips
+    // to memory -- the walk of 7 % of a tile's alignments by one wave was a third of a tile's time.
+    constexpr uint32_t STASH = HT / 8;
     unsigned long long merged_acc = 0;            // thread 0: records merged into others by this block
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + (uint64_t)BT * RPT - 1) / ((uint64_t)BT * RPT);
@@ -1134,16 +1150,19 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         load_read_ctx(p, aln, i, c, nc, off, err);
     };
 
+    IPX_ST_DECL;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        IPX_ST_START;
         unsigned long long my_err = IPX_ERRW_NONE;
         if (t == 0) { pool_n = 0; cx_n = 0; }
-        if (p.combine)
-            for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
         __syncthreads();
         // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one; see the
         // comments inside.  final_pass: survivors go to the record arrays; else they close ranks inside the pool so
         // that the tile can go on filling it (recombine: the pool may hold records an earlier pass made of several).
         auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
+            // (until now the table's words held the walk contexts of phase 2, see STASH)
+            for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
+            __syncthreads();
             // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
             // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
             // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
@@ -1169,15 +1188,38 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     const bool same = live && it.x == fx && it.y == fy && it.z == fz;
                     const unsigned long long sm = ipx_ballot(same);
                     if (__popcll(sm) >= 8) {
-                        unsigned long long o = same ? ord : ~0ull;
-                        uint32_t l = same ? lo : ~0u, h = same ? hi : 0u;
+                        // In a pile-up the first lane usually holds the extremes already (pool slots follow the
+                        // reads' order, copies of one key share the position and mostly the anchors): a compare and
+                        // a ballot per field tell, and the six-level butterflies (84 instructions for the three
+                        // fields) run only for a field some lane improves.
+                        const unsigned long long ord_f = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(ord >> 32), f) << 32) |
+                                                         __builtin_amdgcn_readlane((uint32_t)ord, f);
+                        const uint32_t lo_f = __builtin_amdgcn_readlane(lo, f), hi_f = __builtin_amdgcn_readlane(hi, f);
+                        unsigned long long o = ord_f;
+                        uint32_t l = lo_f, h = hi_f;
+                        if (ipx_ballot(same && ord < ord_f)) {
+                            o = same ? ord : ~0ull;
 #pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) {
-                            const unsigned long long o2 = __shfl_xor(o, d);
-                            const uint32_t l2 = __shfl_xor(l, d), h2 = __shfl_xor(h, d);
-                            o = o2 < o ? o2 : o;
-                            l = l2 < l ? l2 : l;
-                            h = h2 > h ? h2 : h;
+                            for (int d = 32; d >= 1; d >>= 1) {
+                                const unsigned long long o2 = __shfl_xor(o, d);
+                                o = o2 < o ? o2 : o;
+                            }
+                        }
+                        if (ipx_ballot(same && lo < lo_f)) {
+                            l = same ? lo : ~0u;
+#pragma unroll
+                            for (int d = 32; d >= 1; d >>= 1) {
+                                const uint32_t l2 = __shfl_xor(l, d);
+                                l = l2 < l ? l2 : l;
+                            }
+                        }
+                        if (ipx_ballot(same && hi > hi_f)) {
+                            h = same ? hi : 0u;
+#pragma unroll
+                            for (int d = 32; d >= 1; d >>= 1) {
+                                const uint32_t h2 = __shfl_xor(h, d);
+                                h = h2 > h ? h2 : h;
+                            }
                         }
                         uint32_t c0, c1, c2;
                         if (!recombine) {                                           // one read per lane: count lanes
@@ -1307,7 +1349,6 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 #pragma unroll
                 for (uint32_t r = 0; r < CR; ++r)
                     if (live_r[r]) { pool_item[pos_r[r]] = it2[r]; pool_pay[pos_r[r]] = py2[r]; }
-                for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
                 if (t == 0) {
                     pool_n = n_out;
                     merged_acc += total - n_out;
@@ -1350,6 +1391,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r)
             load_ctx(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, c_r[r], nc_r[r], off_r[r], my_err);
+        IPX_ST_LAP(0);                      // attributes arrived (the loads' issue + first use)
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
             w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
@@ -1371,8 +1413,16 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 uint32_t base = 0;
                 if ((int)lane == first) base = atomicAdd(&cx_n, (uint32_t)__popcll(wm));
                 base = __shfl(base, first);
-                if (walk_it) cx_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))] =
-                    (uint16_t)(r * BT + t);
+                if (walk_it) {
+                    const uint32_t li = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                    cx_list[li] = (uint16_t)(r * BT + t);
+                    if (li < STASH) {
+                        uint4 *st = reinterpret_cast<uint4 *>(ht) + 2 * li;
+                        st[0] = make_uint4((uint32_t)c.pos, c.rank, c.strand | (c.cat << 8) | (c.read_rejected ? 0x400u : 0u) | ((nc < 255u ? nc : 255u) << 16),
+                                           off_r[r]);
+                        st[1] = w3;
+                    }
+                }
             }
             // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, then either finish(): one record, or N: the record,
             // its right anchor becomes the next left anchor, -> INTRON, M: -> RIGHT, finish(): the second record
@@ -1422,6 +1472,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             }
         }
         __syncthreads();
+        IPX_ST_LAP(1);                      // phase 1: CIGAR words, closed forms, pool writes, barrier
         // Phase 2: the listed alignments, 64 per wave
         const uint32_t n_walk = cx_n;
         // (room for their records -- up to three from eight ops -- if the closed forms nearly filled the pool)
@@ -1438,12 +1489,28 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             const uint64_t i = tile * ((uint64_t)BT * RPT) + (mine ? cx_list[k0 + lane] : 0u);
             ReadCtx c;
             uint32_t nc = 0, off = 0;
-            unsigned long long seen = IPX_ERRW_NONE;         // gate errors were reported in phase 1
-            load_ctx(i, c, nc, off, seen);
-            if (!mine) nc = 0;
+            uint4 wa = make_uint4(0, 0, 0, 0);
+            // from the stash; from memory only for what did not fit it (or when an early combine used the words)
+            const bool stashed = mine && !recombined && k0 + lane < STASH;
+            if (ipx_ballot(mine && !stashed)) {
+                unsigned long long seen = IPX_ERRW_NONE;     // gate errors were reported in phase 1
+                load_ctx(i, c, nc, off, seen);
+                if (!mine) nc = 0;
+                wa = load_cigar4(cigar, tail, n_words, (nc != 0 && nc <= 8) ? (uint64_t)off : 0ull);
+            }
+            if (stashed) {
+                const uint4 *st = reinterpret_cast<const uint4 *>(ht) + 2 * (k0 + lane);
+                const uint4 s0 = st[0];
+                c.pos = (int32_t)s0.x; c.rank = s0.y; c.strand = s0.z & 0xffu; c.cat = (s0.z >> 8) & 3u;
+                c.read_rejected = (s0.z & 0x400u) != 0;
+                c.read_index = base_read_index + i;
+                c.flag = 0; c.nhc = 0;
+                nc = s0.z >> 16;
+                off = s0.w;
+                wa = st[1];
+            }
             const bool small = nc != 0 && nc <= 8;
-            // both chunks always (a lane without a short CIGAR reads the array's first words)
-            const uint4 wa = load_cigar4(cigar, tail, n_words, small ? (uint64_t)off : 0ull);
+            // (a lane without a CIGAR of five to eight words reads the array's first words)
             const uint4 wb = load_cigar4(cigar, tail, n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
             const uint32_t pos32 = (uint32_t)c.pos;
 
@@ -1560,6 +1627,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         }
         __syncthreads();
         const uint32_t total = pool_n;
+        IPX_ST_LAP(2);                      // phase 2: walks
         if (total <= POOL && !p.combine) {
             if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
@@ -1617,7 +1685,16 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         }
         if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
         __syncthreads();
+        IPX_ST_LAP(3);                      // combine + reservation + copy-out
+#ifdef IPX_SCAN_STATS
+        ++st_tiles;
+#endif
     }
+#ifdef IPX_SCAN_STATS
+    if (t == 0 && (blockIdx.x % 199) == 0)
+        printf("block %u: %u tiles; cycles per tile: attributes %llu, phase 1 %llu, walks %llu, combine + copy-out %llu\n", blockIdx.x,
+               st_tiles, st_ph[0] / st_tiles, st_ph[1] / st_tiles, st_ph[2] / st_tiles, st_ph[3] / st_tiles);
+#endif
     if (t == 0 && merged_acc)
         atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED), merged_acc);
     uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};

@@ -1,0 +1,8 @@
+cd "$GRAFT_REPO_ROOT"
+for i in 1 2 3; do
+for lib in profiles/microbench/libipx_prev.so intronprospector_amd/libipx.so; do
+IPX_LIB_PATH=$PWD/$lib python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-configs --no-parity 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('$lib', round(d['ms_per_step'],4), 'scan', round(r['kernels_ms_per_step']['k_scan']*1e3,1))"
+done; done

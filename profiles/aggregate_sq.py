@@ -3,7 +3,7 @@ usage: python profiles/aggregate_sq.py gpurun_out/pmc_sq1 [gpurun_out/pmc_sq2 ..
 import csv, glob, collections, sys
 agg = collections.defaultdict(lambda: [0.0, 0])
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
             agg[(k, r["Counter_Name"])][0] += float(r["Counter_Value"])

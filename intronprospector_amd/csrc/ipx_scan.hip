@@ -1019,6 +1019,448 @@ __global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n,
     }
 }
 
+// ---- long CIGARs, third formulation: plain ops at a few instructions each, events on a fixed beat ----
+// Nineteen ops in twenty of a long read only lengthen the anchor the walk is in (M = X, and I / D below the
+// indel limit, while the state is LEFT or RIGHT; junctions_extractor.cc:232-275): they move tp / ae and add to
+// one counter.  k_scan_long pays the whole state machine (~90 vector instructions) for each of them.  Here a
+// TURN of the wave is one step of the full state machine, one step that knows only the M after an N (or after a
+// clip: the op that opens an anchor, ~25 instructions), and LONG3_FAST "plain" steps (~30 instructions: no state,
+// no snapshot, no drain).  A lane that meets anything else in a plain step (N, a clip, an indel run over the
+// limit, its alignment's last op) stands still until the next turn's full step -- a few steps' wait once per
+// junction, where k_scan_long2 let it wait for 40 other lanes.
+// Lanes advance at their own pace, so the CIGAR words go through a per-lane ring in LDS (32 words a lane, word-
+// major: no bank conflicts; row = the word's index in the CIGAR array mod 32, so the ring holds two ALIGNED 64-byte
+// pieces of the array).  A lane asks for its next piece -- four 16-byte loads issued back to back -- as soon as
+// the piece two before it is used up; the loads land in registers and move to the ring at the top of the next
+// turn.  The memory side is why: with a 16-byte load per lane every four ops (k_scan_long) each lane's 128-byte
+// line is asked for eight times over ~30 us, and the lines of the 32 k lanes an XCD runs are exactly its 4 MB of
+// L2 -- PMC: 24 GB from the fabric per 2 M alignments for 6.6 GB of CIGAR words, 4.5 TB/s, which is what bounds
+// that kernel (profiles/long_occupancy_experiment.sh: fewer waves per CU = proportionally less traffic).  Here a
+// line is asked for twice, once per half.
+constexpr uint32_t LONG3_POOL = 96;          // records per wave pool (1.5 KB + 1.5 KB)
+constexpr uint32_t LONG3_RINGW = 32;         // CIGAR words per lane in the LDS ring (two aligned pieces of 16)
+constexpr uint32_t LONG3_DRAIN = 40;         // waiting snapshots that trigger a drain
+constexpr uint32_t LONG3_FAST = 6;           // plain steps per turn: LONG3_FAST + 2 ops = half a piece, a piece arrives within a turn
+
+__global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
+                                                   uint32_t reads_per_wave,
+                                                   const int32_t *__restrict__ a_tid,
+                                                   const int32_t *__restrict__ a_pos,
+                                                   const uint16_t *__restrict__ a_flag,
+                                                   const uint8_t *__restrict__ a_xs,
+                                                   const uint8_t *__restrict__ a_nh,
+                                                   const uint32_t *__restrict__ a_off,
+                                                   const uint32_t *__restrict__ a_nc,
+                                                   const uint32_t *__restrict__ cigar,
+                                                   const uint32_t *__restrict__ tail,
+                                                   const uint32_t *__restrict__ rank_of_tid,
+                                                   uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                                   uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
+                                                   uint64_t capacity, Counters *counters) {
+    static_assert(LONG3_FAST + 2 <= LONG3_RINGW / 4, "a piece asked for at the top of a turn must be there before the lane needs it");
+    __shared__ uint4 pool_item[4][LONG3_POOL], pool_pay[4][LONG3_POOL];
+    __shared__ LongStage stage_s[4];
+    __shared__ uint32_t ring_s[4][LONG3_RINGW][64];   // per lane (column): its next CIGAR words, word w of the array in row w % 32
+    __shared__ uint32_t kb_s[4][6];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint4 *const my_item = pool_item[wave], *const my_pay = pool_pay[wave];
+    LongStage &stage = stage_s[wave];
+    uint32_t (*const my_ring)[64] = ring_s[wave];
+    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
+    unsigned long long my_err = IPX_ERRW_NONE;
+
+    auto load4 = [&](uint64_t w) { return load_cigar4(cigar, tail, n_words, w); };
+
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
+    uint64_t next = gw * reads_per_wave;          // wave-uniform from here on
+    uint64_t range_end = next + reads_per_wave;
+    if (range_end > n) range_end = n;
+    if (next > n) next = n;
+    uint32_t staged = 0, staged_used = 0;         // alignments in the stage / already handed out
+    uint32_t pool_n = 0;
+    const uint32_t stripe = my_stripe(p);
+
+    auto flush = [&]() {
+        __threadfence_block();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(append_counter(counters, p, stripe), (unsigned long long)pool_n);
+        base = __shfl(base, 0);
+        for (uint32_t k = lane; k < pool_n; k += 64) {
+            const uint64_t idx = append_index(p, stripe, base + k);
+            if (idx < capacity) {
+                uint4 it = my_item[k];
+                it.w = (uint32_t)idx;
+                items[idx] = it;
+                const uint4 py = my_pay[k];
+                pays[idx] = py;
+                cnts[idx] = IPX_CNT_ONE(py.x & 3u);
+                digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+            }
+        }
+        __threadfence_block();
+        pool_n = 0;
+    };
+
+    // ---- per-lane state of the alignment being walked
+    bool active = false, pending = false, redo = false;
+    bool fin = false;                             // the waiting junction is the alignment's last: it sits in the
+                                                  // walk's own registers, not in the snapshot
+    uint64_t my_i = 0;                            // alignment index in the batch
+    uint32_t pos32 = 0, meta = 0, rank = 0;       // meta: strand | cat << 8 | read_rejected << 10
+    uint32_t cw = 0, end_w = 0;                   // word (of the CIGAR array) of the next op to apply / one past the alignment's last
+    uint32_t off0 = 0;                            // first word of the alignment's CIGAR
+    uint32_t hf = 0;                              // next 16-word piece of the array to ask for; pieces before it are in the ring or used up
+    uint4 land[4];                                // the piece in flight
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) land[k] = make_uint4(0, 0, 0, 0);
+    bool in_flight = false;
+    uint32_t state = ST_LIMBO;
+    uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;          // offsets from the alignment's pos
+    uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
+    uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;   // snapshot of a finished junction
+#ifdef IPX_LONG3_STATS
+    uint32_t st_turns = 0, st_plain = 0, st_full = 0, st_entry = 0, st_active = 0, st_starved = 0;
+#endif
+
+    // junction_qc, junctions_extractor.cc:392-397, on a snapshot (offsets are exact and ordered)
+    auto snap_ok = [&]() {
+        const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
+        const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
+        const uint32_t ilen = q_ie - q_is;
+        return !(meta & 0x400u) && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
+               (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
+               (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
+    };
+
+    // QC, pack and store the waiting snapshots of the whole wave (pool -> record arrays when the pool fills up)
+    auto drain = [&]() {
+        const bool pass = pending && snap_ok();
+        const unsigned long long em = ipx_ballot(pass);
+        if (pass) {
+            const uint32_t slot = pool_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+            const unsigned long long ri = base_read_index + my_i;
+            if (ordinal <= IPX_ORD_MAX_ORDINAL) {
+                ReadCtx c;
+                c.pos = 0; c.rank = rank; c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_index = ri;
+                uint4 it, pay;
+                const Rec r{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
+                            (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
+                pack_record_rel(p, c, r, pos32, ordinal, it, pay);
+                my_item[slot] = it;
+                my_pay[slot] = pay;
+            }
+            if (++ordinal > IPX_ORD_MAX_ORDINAL) {
+                const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 1u;
+                my_err = e < my_err ? e : my_err;
+            }
+        }
+        pending = false;
+        fin = false;
+        pool_n += (uint32_t)__popcll(em);
+        if (pool_n > LONG3_POOL - 64) flush();
+    };
+
+    // ---- the full state machine: one op for every lane with `go` (k_scan_long's step)
+    auto step = [&](uint32_t w, bool go) {
+        const uint32_t left = end_w - cw;
+        const bool run = go && active && left != 0;
+        const uint32_t op = w & 0xfu, len = w >> 4;
+        // BAM_CIGAR_STR "MIDNSHP=XB": M0 I1 D2 N3 S4 H5 P6 =7 X8 B9; classes 1 = M/=/X, 2 = N, 4 = I/D, 8 = S/H
+        const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
+        const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
+        const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
+        // I/D :257-275: counters first, then the test
+        lind += (c_id && in_l) ? len : 0u;
+        rind += (c_id && in_r) ? len : 0u;
+        const uint32_t indel2 = cur_indel + len;
+        const bool over = c_id && indel2 > p.max_anchor_indel_size;
+        // the op ends a junction: N :208-229, S/H :306-311, I/D beyond the limit
+        const bool trig = in_r && (c_n || c_sh || over);
+        const bool last = run && left == 1;                             // finish() :278-282 follows this op
+
+        // ---- store waiting snapshots: when one is about to be overwritten or orphaned, or enough wait
+        const unsigned long long pm = ipx_ballot(pending);
+        if (pm && (ipx_ballot(pending && (trig || last || !active)) || __popcll(pm) >= (int)LONG3_DRAIN)) drain();
+        s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
+        s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
+        pending = pending || trig;
+
+        // ---- apply the op
+        const uint32_t tpn = tp + len;
+        const bool adv = c_m || c_n || (c_id && op == 2);               // M = X N D move along the reference
+        const bool carry = adv && tpn < tp;
+        const bool bad = run && cls == 0;
+        if (ipx_ballot(carry || bad)) {                                    // rare, wave-uniform
+            if (carry) {                                                 // offsets leave 32 bits: 64-bit re-run
+                if (trig) pending = false;                               // this op's junction comes from the re-run too
+                redo = true;
+            } else if (bad) {                                            // :312-313: the exception ends the read
+                const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
+                const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
+                const unsigned long long e = ((base_read_index + my_i) << IPX_ORD_SHIFT_READ) |
+                                             ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
+                                             (IPX_ERRK_CIGAR << 8) | ch;
+                my_err = e < my_err ? e : my_err;
+            }
+        }
+        const bool n_r = c_n && in_r;                                   // N closes a junction's right anchor ...
+        const bool n_lr = c_n && (in_l || in_r);                        // ... and opens the next intron
+        const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
+        const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
+        const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
+        is = n_lr ? tp : is;
+        as = as2;
+        ie = ie2;
+        ae = c_m ? tpn : ae;
+        uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);               // M from LIMBO zeroes the mismatch counters
+        uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;                    // only: indel counters keep their value
+        lind = n_r ? rind : lind;
+        rind = n_r ? 0u : rind;
+        state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
+        const bool x = c_m && op == 8;                                  // state is LEFT or RIGHT after an M
+        lmm2 += (x && state == ST_LEFT) ? len : 0u;
+        rmm2 += (x && state == ST_RIGHT) ? len : 0u;
+        lmm = lmm2;
+        rmm = rmm2;
+        cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
+        tp = adv ? tpn : tp;
+        // finish(): the alignment's last op leaves a right anchor open (never together with `trig`: an op
+        // that ends a junction does not leave the walk in RIGHT).  The lane stops here, so the junction
+        // stays where it is until the next drain -- which is the next full step's, the lane being inactive
+        fin = go ? (last && !carry && !bad && state == ST_RIGHT) : fin;
+        pending = pending || fin;
+        cw += run ? 1u : 0u;
+        active = go ? (run && !last && !carry && !bad) : active;
+    };
+
+    for (;;) {
+        // ---- 64-bit re-run of alignments whose offsets left 32 bits (after their snapshot is stored)
+        if (ipx_ballot(redo && !pending)) {
+            if (redo && !pending) {
+                ReadCtx c;
+                c.pos = (int32_t)pos32; c.flag = 0; c.nhc = 0; c.rank = rank;
+                c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
+                c.read_index = base_read_index + my_i;
+                (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, cnts, digs, kb,
+                                  my_err, append_counter(counters, p, stripe), stripe);
+                redo = false;
+            }
+        }
+        // ---- hand out alignments
+        const unsigned long long idle = ipx_ballot(!active && !pending && !redo);
+        if (idle) {
+            if (next >= range_end) {
+                if (idle == ~0ull) break;
+            } else {
+                if (staged_used == staged) {
+                    // stage the next 64 alignments: process_alignment gate (junctions_extractor.cc:533-536),
+                    // strand and category
+                    const uint64_t rem = range_end - next;
+                    staged = rem < 64 ? (uint32_t)rem : 64u;
+                    staged_used = 0;
+                    if (lane < staged) {
+                        const uint64_t i = next + lane;
+                        const int32_t tid = a_tid[i];
+                        uint32_t ncl = a_nc[i];
+                        const uint32_t flag = a_flag[i];
+                        const unsigned long long ri = base_read_index + i;
+                        if (ncl <= 1 || tid < 0 || (flag & (F_QCFAIL | F_DUP))) ncl = 0;
+                        if (ncl && (uint32_t)tid >= p.n_targets) {
+                            const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
+                            my_err = e < my_err ? e : my_err;
+                            ncl = 0;
+                        }
+                        const uint32_t off = ncl ? a_off[i] : 0u;
+                        if (ncl && (uint64_t)off + ncl > n_words) {          // words outside the batch
+                            const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
+                            my_err = e < my_err ? e : my_err;
+                            ncl = 0;
+                        }
+                        stage.nc[lane] = ncl;
+                        if (ncl) {
+                            const uint32_t nhc = a_nh[i], xs = a_xs[i];
+                            const uint32_t strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(flag, p.strandness)
+                                                                                     : (xs ? xs : (uint32_t)'.');
+                            const uint32_t rej = ((flag & F_SECONDARY) || (p.exclude_multi && nhc == 2)) ? 0x400u : 0u;
+                            stage.pos[lane] = (uint32_t)a_pos[i];
+                            stage.meta[lane] = strand | (read_category(flag, nhc) << 8) | rej;
+                            stage.rank[lane] = p.rank_is_tid ? (uint32_t)tid : rank_of_tid[tid];
+                            stage.off[lane] = off;
+                        }
+                    }
+                    __threadfence_block();
+                }
+                const uint32_t avail = staged - staged_used;
+                if (!active && !pending && !redo) {
+                    const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (e < avail) {
+                        const uint32_t k = staged_used + e;
+                        const uint32_t ncl = stage.nc[k];
+                        if (ncl) {
+                            my_i = next + e;
+                            pos32 = stage.pos[k];
+                            meta = stage.meta[k];
+                            rank = stage.rank[k];
+                            off0 = stage.off[k];
+                            cw = off0;
+                            end_w = off0 + ncl;
+                            hf = off0 >> 4;
+                            in_flight = false;
+                            state = ST_LIMBO;
+                            tp = as = is = ie = ae = 0;
+                            lmm = rmm = lind = rind = cur_indel = ordinal = 0;
+                            active = true;
+                        }
+                    }
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t took = want < avail ? want : avail;
+                staged_used += took;
+                next += took;
+            }
+        }
+        // ---- (1) the piece the landing registers took up a turn ago goes to its ring rows
+        if (in_flight) {
+            const uint32_t r0 = ((hf - 1u) & 1u) * 16u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                my_ring[r0 + 4 * k][lane] = land[k].x; my_ring[r0 + 4 * k + 1][lane] = land[k].y;
+                my_ring[r0 + 4 * k + 2][lane] = land[k].z; my_ring[r0 + 4 * k + 3][lane] = land[k].w;
+            }
+        }
+        const uint32_t have_w = hf * 16u;                          // words [cw, have_w) of the array are in the ring
+        // ---- (2) the next piece, if the alignment reaches into it and the piece whose rows it takes is used up
+        {
+            const bool want = active && have_w < end_w && cw + 16u >= have_w;
+            if (want) {
+                if ((uint64_t)have_w + 16u <= n_words) {                     // the whole piece is inside the array (it is 16-byte aligned)
+                    const uint4 *src = reinterpret_cast<const uint4 *>(cigar + have_w);
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) land[k] = src[k];
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint64_t w = (uint64_t)have_w + 4u * k;
+                        land[k] = load4(w < n_words ? w : (uint64_t)off0);   // (a chunk past the array's end: any words will do)
+                    }
+                }
+                hf += 1u;
+            }
+            in_flight = want;
+        }
+        // ---- (3) one full step: whatever made a lane stop in the last turn's plain steps (for the others, one more op)
+        {
+            const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
+            const bool go = active && cw < have_w;
+#ifdef IPX_LONG3_STATS
+            st_full += __popcll(ipx_ballot(go)); st_starved += __popcll(ipx_ballot(active && !go));
+#endif
+            step(w, go);
+        }
+        // the ops the lane may take without the full step this turn: words in the ring, never the alignment's last
+        // op (finish() follows it), and only while the turn's ops cannot carry out of 32 bits (lengths are 28 bits)
+        const uint32_t lim1 = (active && tp < 0x40000000u) ? (have_w < end_w - 1u ? have_w : end_w - 1u) : 0u;
+        // ---- (4) the op after an N (or after a clip, or the alignment's first): M = X from INTRON opens the right
+        // anchor, from LIMBO the left one (:232-255) -- k_scan_long's step for exactly this case
+        {
+            const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
+            const uint32_t op = w & 0xfu, len = w >> 4;
+            const uint32_t code = (uint32_t)(0x0000000D50000325ull >> (op * 4u));
+            const bool ok = cw < lim1 && (code & 4u) != 0u && (state & (ST_LIMBO | ST_INTRON)) != 0u;
+            if (ok) {
+                const bool from_limbo = state == ST_LIMBO;
+                const uint32_t xl = len & (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
+                as = from_limbo ? tp : as;
+                ie = from_limbo ? ie : tp;
+                lmm = from_limbo ? xl : lmm;                            // M from LIMBO zeroes the mismatch counters only
+                rmm = from_limbo ? 0u : rmm + xl;
+                state = from_limbo ? ST_LEFT : ST_RIGHT;
+                tp += len;
+                ae = tp;
+                cur_indel = 0;
+                cw += 1u;
+            }
+#ifdef IPX_LONG3_STATS
+            st_entry += __popcll(ipx_ballot(ok));
+#endif
+        }
+        // ---- (5) plain steps: only from LEFT / RIGHT, which no plain op leaves
+        {
+            const bool lr = (state & (ST_LEFT | ST_RIGHT)) != 0u;
+            const uint32_t lim = lr ? lim1 : 0u;
+            const uint32_t m_l = state == ST_LEFT ? ~0u : 0u;
+            uint32_t ind_acc = 0, mm_acc = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < LONG3_FAST; ++k) {
+                const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
+                const uint32_t op = w & 0xfu, len = w >> 4;
+                // bit 0: moves along the reference (M = X D), bit 1: indel (I D), bit 2: M = X, bit 3: X; 0: not a plain op
+                const uint32_t code = (uint32_t)(0x0000000D50000325ull >> (op * 4u));
+                const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
+                               m_m = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
+                const uint32_t tpn = tp + (len & m_adv);
+                const uint32_t il = len & m_id;
+                const uint32_t ci = (cur_indel + il) & ~m_m;             // I/D :257-275 add up, M = X :232-255 start over
+                const bool ok = cw < lim && (code & 0xfu) != 0u && ci <= p.max_anchor_indel_size;
+                if (ok) {
+                    tp = tpn;
+                    ae = (tpn & m_m) | (ae & ~m_m);
+                    cur_indel = ci;
+                    ind_acc += il;
+                    mm_acc += len & m_x;
+                    cw += 1u;
+                }
+#ifdef IPX_LONG3_STATS
+                st_plain += __popcll(ipx_ballot(ok));
+#endif
+            }
+            lind += ind_acc & m_l; rind += ind_acc & ~m_l;
+            lmm += mm_acc & m_l; rmm += mm_acc & ~m_l;
+        }
+#ifdef IPX_LONG3_STATS
+        st_turns++; st_active += __popcll(ipx_ballot(active));
+#endif
+    }
+    if (pool_n) flush();
+#ifdef IPX_LONG3_STATS
+    if (lane == 0 && (gw % 997) == 0)
+        printf("wave %llu: turns %u plain-ops %u full-ops %u entry-ops %u active-lanes %u starved %u\n",
+               (unsigned long long)gw, st_turns, st_plain, st_full, st_entry, st_active, st_starved);
+#endif
+
+    unsigned long long e = my_err;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(e, d);
+        e = o < e ? o : e;
+    }
+    if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+
+    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const uint32_t o = __shfl_xor(v[k], dlt);
+            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
+        }
+        if (lane == 0) kb_s[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (t < 6) {
+        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
+        if (t < 3) {
+            const uint32_t o = x0 | x1 | x2 | x3;
+            if (o) atomicOr(&counters->key_or[t], o);
+        } else {
+            const uint32_t a = x0 & x1 & x2 & x3;
+            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+        }
+    }
+}
+
 // ---- short CIGARs, second generation ------------------------------------------------------------
 // k_scan_short: k_scan's tile structure (one lane per alignment, RPT alignments per thread, records
 // staged in an LDS pool, ONE global atomic per tile) around the select-based walk of k_scan_long.  A
@@ -1949,7 +2391,10 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
             const long v = e ? atol(e) : 0;
             return (uint32_t)(v >= 64 && v <= 65536 ? v : 64);
         }();
-        const uint64_t max_waves = 256ull * 4 * 4;      // all resident at once (128 VGPRs: 4 waves per SIMD)
+        const char *lv = getenv("IPX_LONG");
+        // k_scan_long3 reads aligned 64-byte pieces of the CIGAR array and counts its words in 32 bits
+        const bool v3 = !(lv && (lv[0] == '1' || lv[0] == '2')) && ((uintptr_t)b.cigar & 15u) == 0 && b.n_cigar_words < (1ull << 31);
+        const uint64_t max_waves = 256ull * 4 * (v3 ? 3 : 4);      // all resident at once (128 VGPRs: 4 waves per SIMD; k_scan_long3: 3, by its LDS)
         uint64_t per_wave = ipx_div_up(b.n_alignments, max_waves);
         if (per_wave < min_range) per_wave = min_range;
         // few alignments per lane: whole multiples of 64, or one lane's second alignment doubles the wave's time
@@ -1960,9 +2405,14 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         // anything else wait for a common op-by-op turn).  Exact (tests run both) but slower on the ONT-style
         // workload, 6.5 against 5.1 ms at 2 M alignments: a sixth of the chunks need the slow turn, so it runs every
         // five or six fast turns at 60 % of the lanes, and a fast turn costs ~280 instructions, not the ~100 planned
-        const char *lv = getenv("IPX_LONG");
-        if (!(lv && lv[0] == '2'))
-            hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
+        const char *lp = getenv("IPX_LONG_PAD");                  // experiment: extra LDS per block = fewer waves per CU
+        const uint32_t pad = lp ? (uint32_t)atol(lp) : 0u;
+        if (v3)
+            hipLaunchKernelGGL(k_scan_long3, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
+                               b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
+                               b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
+        else if (!(lv && lv[0] == '2'))
+            hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
         else

@@ -224,6 +224,36 @@ int ipx_push_batch(ipx_handle *h, const ipx_batch *batch);
  * Stands for the same process_alignment loop (junctions_extractor.cc:533-549,656-664). */
 int ipx_push_batch_async(ipx_handle *h, const ipx_batch *batch);
 int ipx_sync(ipx_handle *h);
+
+/* A batch as the caller's BAM reader holds it: alignment records of the BAM stream (SAM spec 4.2, each with its
+ * block_size word: refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen,
+ * read_name, cigar, seq, qual, tags), back to back in `bytes`.  The device reads of each record what
+ * process_alignment reads of a bam1_t (junctions_extractor.cc:533-549): core.tid, core.pos, core.flag, the CIGAR
+ * (bam_get_cigar; the CG tag's words behind a "<l_seq>S<n>N" placeholder, SAM spec 4.2.2), bam_aux_get("XS") +
+ * bam_aux2A (:322-330), bam_aux_get("NH") + bam_aux2i (:49-56) -- so a caller needs no per-record loop of its
+ * own.  The caller only says where runs of whole records lie: span k is bytes [span_begin[k], span_begin[k+1])
+ * and holds records span_first[k] .. span_first[k+1]-1 of the batch (an inflated BGZF block, minus the record
+ * that straddles its end, is one span; both tables have n_spans + 1 entries, start at 0 and end at n_bytes /
+ * n_alignments).  tid_map (or NULL): refID -> the tid the hot path is to see.  n_cigar_words: the CIGAR words
+ * of all records (CG-tag CIGARs counted as such); a count the records do not bear out, and any record that does
+ * not parse (what sam_read1 returns < -1 for), makes the completing call return IPX_EINVAL with the batch dropped.
+ * memory: IPX_MEM_HOST (pinned memory from ipx_host_alloc for an asynchronous copy).  Otherwise as ipx_push_batch /
+ * ipx_push_batch_async. */
+typedef struct ipx_bam_batch {
+    uint64_t n_alignments;
+    uint64_t n_cigar_words;
+    uint64_t base_read_index;
+    const uint8_t  *bytes;
+    uint64_t n_bytes;
+    const uint64_t *span_begin;
+    const uint64_t *span_first;
+    uint32_t n_spans;
+    const int32_t  *tid_map;
+    uint32_t n_tid_map;
+    int32_t memory;
+} ipx_bam_batch;
+int ipx_push_bam(ipx_handle *h, const ipx_bam_batch *batch);
+int ipx_push_bam_async(ipx_handle *h, const ipx_bam_batch *batch);
 /* pinned (page-locked) host memory, hipHostMalloc / hipHostFree */
 int ipx_host_alloc(void **out, size_t bytes);
 int ipx_host_free(void *p);

@@ -29,6 +29,7 @@ SYMBOLS = [
     "ipx_group_set_option", "ipx_group_push_batch", "ipx_group_finalize", "ipx_group_clear",
     "ipx_group_last_error", "ipx_group_uses_rccl",
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
+    "ipx_push_bam", "ipx_push_bam_async",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -48,6 +49,14 @@ class Batch(C.Structure):
         ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p), ("xs", C.c_void_p),
         ("nh", C.c_void_p), ("cigar_off", C.c_void_p), ("n_cigar", C.c_void_p), ("cigar", C.c_void_p),
         ("memory", C.c_int32),
+    ]
+
+
+class BamBatch(C.Structure):
+    _fields_ = [
+        ("n_alignments", C.c_uint64), ("n_cigar_words", C.c_uint64), ("base_read_index", C.c_uint64),
+        ("bytes", C.c_void_p), ("n_bytes", C.c_uint64), ("span_begin", C.c_void_p), ("span_first", C.c_void_p),
+        ("n_spans", C.c_uint32), ("tid_map", C.c_void_p), ("n_tid_map", C.c_uint32), ("memory", C.c_int32),
     ]
 
 
@@ -100,6 +109,8 @@ def load():
     lib.ipx_push_batch.argtypes = [vp, C.POINTER(Batch)]
     lib.ipx_push_batch_async.argtypes = [vp, C.POINTER(Batch)]
     lib.ipx_sync.argtypes = [vp]
+    lib.ipx_push_bam.argtypes = [vp, C.POINTER(BamBatch)]
+    lib.ipx_push_bam_async.argtypes = [vp, C.POINTER(BamBatch)]
     lib.ipx_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.ipx_host_free.argtypes = [vp]
     lib.ipx_finalize.argtypes = [vp, C.c_int32, C.POINTER(Table)]

@@ -105,6 +105,7 @@ struct PendingPush {
     Counters before{};           // counters to return to if the scan has to be repeated
     bool use_ops = false, use_stripes = true;
     int attempt = 0;
+    bool is_bam = false;         // the batch came as BAM records (ipx_push_bam): the decode's error word counts
 };
 
 struct ipx_handle {
@@ -140,7 +141,7 @@ struct ipx_handle {
     // holds records; an empty handle takes `first_hint`: the window the last sort would have liked
     // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
     DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
-    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws, defer;
+    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws, defer, bam_raw;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
     uint32_t *mail_host = nullptr, *mail_dev = nullptr;      // k_publish's mailbox (pinned, host-coherent)
@@ -480,7 +481,7 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->d_rank_seq, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
-                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer})
+                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer, &h->bam_raw})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->mail_host) (void)hipHostFree(h->mail_host);
@@ -593,6 +594,8 @@ static int launch_scan_attempt(ipx_handle *h) {
     return read_back_begin(h, h->counters.p, sizeof(Counters) / 4, defer_n_dev, 4);
 }
 
+static int push_launch(ipx_handle *h);
+
 static int push_begin(ipx_handle *h, const ipx_batch *b) {
     const uint64_t n = b->n_alignments, nw = b->n_cigar_words;
     if (!b->tid || !b->pos || !b->flag || !b->xs || !b->nh || !b->cigar_off || !b->n_cigar || (nw && !b->cigar))
@@ -629,7 +632,15 @@ static int push_begin(ipx_handle *h, const ipx_batch *b) {
     } else if (b->memory != IPX_MEM_DEVICE) {
         return IPX_EINVAL;
     }
+    pp.is_bam = false;
+    return push_launch(h);
+}
 
+// the batch is in device memory (pp.db): make room for its records, set the scan up and queue it
+static int push_launch(ipx_handle *h) {
+    PendingPush &pp = h->pending;
+    const uint64_t n = pp.n, nw = pp.nw;
+    int rc;
     // capacity: a record needs at least two CIGAR words (xM yN zM -> 1 record per extra 2 words)
     const uint64_t upper = nw / 2;
     uint64_t guess = 2 * n + 1024;
@@ -680,6 +691,64 @@ static int push_begin(ipx_handle *h, const ipx_batch *b) {
     return IPX_OK;
 }
 
+// ---- ipx_push_bam: the batch arrives as BAM records; ipx_bam.hip turns them into the SoA the scan reads
+static int push_begin_bam(ipx_handle *h, const ipx_bam_batch *b) {
+    const uint64_t n = b->n_alignments, nw = b->n_cigar_words;
+    if (!b->bytes || !b->span_begin || !b->span_first || b->n_spans == 0 || (b->n_tid_map && !b->tid_map))
+        return fail(h, IPX_EINVAL, "ipx_push_bam: null array%s%ld", "", 0);
+    if (b->memory != IPX_MEM_HOST) return fail(h, IPX_EINVAL, "ipx_push_bam: the records must be in host memory%s%ld", "", 0);
+    if (b->base_read_index + n > IPX_ORD_MAX_READ)
+        return fail(h, IPX_EINVAL, "read index beyond 2^34-1%s%ld", "", 0);
+    if (nw >= (1ull << 32) || n >= (1ull << 32) - 2)
+        return fail(h, IPX_EINVAL, "more than 2^32-1 CIGAR words or alignments in one batch%s%ld", "", 0);
+    // the span tables must describe [0, n_bytes) and [0, n): the device trusts nothing else about them
+    if (b->span_begin[0] != 0 || b->span_begin[b->n_spans] != b->n_bytes || b->span_first[0] != 0 || b->span_first[b->n_spans] != n)
+        return fail(h, IPX_EINVAL, "ipx_push_bam: span tables do not cover the batch%s%ld", "", 0);
+    for (uint32_t k = 0; k < b->n_spans; ++k)
+        if (b->span_begin[k] > b->span_begin[k + 1] || b->span_first[k] > b->span_first[k + 1])
+            return fail(h, IPX_EINVAL, "ipx_push_bam: span tables are not ascending%s%ld", "", 0);
+    int rc;
+    PendingPush &pp = h->pending;
+    pp.n = n;
+    pp.nw = nw;
+    auto al = [](uint64_t x) { return (x + 255) & ~255ull; };
+    // raw side: bytes (+ 8: ld32 reads the aligned word pair around any offset), span tables, tid map, workspace
+    const uint64_t r_bytes = 0, r_sb = al(r_bytes + b->n_bytes + 8), r_sf = al(r_sb + 8ull * (b->n_spans + 1)),
+                   r_map = al(r_sf + 8ull * (b->n_spans + 1)), r_ws = al(r_map + 4ull * b->n_tid_map),
+                   r_total = al(r_ws + ipx_bam_workspace_bytes(n));
+    if ((rc = ensure(h, h->bam_raw, r_total))) return rc;
+    char *r = h->bam_raw.as<char>();
+    HIPCHK(hipMemcpyAsync(r + r_bytes, b->bytes, b->n_bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(r + r_bytes + b->n_bytes, 0, 8, h->stream));
+    HIPCHK(hipMemcpyAsync(r + r_sb, b->span_begin, 8ull * (b->n_spans + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(r + r_sf, b->span_first, 8ull * (b->n_spans + 1), hipMemcpyHostToDevice, h->stream));
+    if (b->n_tid_map) HIPCHK(hipMemcpyAsync(r + r_map, b->tid_map, 4ull * b->n_tid_map, hipMemcpyHostToDevice, h->stream));
+    // SoA side: the sections ipx_push_batch stages a host batch into
+    const uint64_t o_tid = 0, o_pos = al(o_tid + n * 4), o_flag = al(o_pos + n * 4), o_xs = al(o_flag + n * 2),
+                   o_nh = al(o_xs + n), o_off = al(o_nh + n), o_nc = al(o_off + n * 4), o_cig = al(o_nc + n * 4),
+                   total = al(o_cig + nw * 4 + 16);
+    if ((rc = ensure(h, h->stage, total))) return rc;
+    char *s = h->stage.as<char>();
+    ipx_batch &db = pp.db;
+    db = ipx_batch{};
+    db.n_alignments = n;
+    db.n_cigar_words = nw;
+    db.base_read_index = b->base_read_index;
+    db.memory = IPX_MEM_DEVICE;
+    db.tid = (const int32_t *)(s + o_tid); db.pos = (const int32_t *)(s + o_pos);
+    db.flag = (const uint16_t *)(s + o_flag); db.xs = (const uint8_t *)(s + o_xs);
+    db.nh = (const uint8_t *)(s + o_nh); db.cigar_off = (const uint32_t *)(s + o_off);
+    db.n_cigar = (const uint32_t *)(s + o_nc); db.cigar = (const uint32_t *)(s + o_cig);
+    uint32_t *bam_err = reinterpret_cast<uint32_t *>(h->counters.as<char>() + IPX_CNT_DEFER) + 1;
+    HIPCHK(ipx_launch_bam_decode(h->stream, (const uint8_t *)(r + r_bytes), (const uint64_t *)(r + r_sb), (const uint64_t *)(r + r_sf),
+                                 b->n_spans, n, nw, b->n_tid_map ? (const int32_t *)(r + r_map) : nullptr, b->n_tid_map,
+                                 (int32_t *)(s + o_tid), (int32_t *)(s + o_pos), (uint16_t *)(s + o_flag), (uint8_t *)(s + o_xs),
+                                 (uint8_t *)(s + o_nh), (uint32_t *)(s + o_off), (uint32_t *)(s + o_nc), (uint32_t *)(s + o_cig),
+                                 r + r_ws, bam_err));
+    pp.is_bam = true;
+    return push_launch(h);
+}
+
 static int push_complete(ipx_handle *h) {
     PendingPush &pp = h->pending;
     if (!pp.active) return IPX_OK;
@@ -696,6 +765,13 @@ static int push_complete(ipx_handle *h) {
         const bool layout_bad = pp.use_ops && c->pad[0] != 0;
         const bool stripes_bad = c->pad[1] != 0;                 // more gaps between the stripes than the lists hold
         const uint32_t n_defer = pp.use_ops ? 0u : tail4[0];
+        if (pp.is_bam && tail4[1] != 0xffffffffu) {
+            // what the host parser throws "Error reader BAM record" for; the scan's records of this batch are dropped
+            const uint32_t bad = tail4[1];
+            hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), pp.before);
+            HIPCHK(hipGetLastError());
+            return fail(h, IPX_EINVAL, "ipx_push_bam: malformed BAM record%s (alignment %ld of the batch)", "", (long)bad - 1);
+        }
         if (getenv("IPX_DEBUG_PLAN"))
             fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away, %u alignments left to the second stage\n",
                     (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged, n_defer);
@@ -745,6 +821,25 @@ int ipx_push_batch_async(ipx_handle *h, const ipx_batch *b) {
     if (rc) return rc;
     if (b->n_alignments == 0) return IPX_OK;
     return push_begin(h, b);
+}
+
+int ipx_push_bam(ipx_handle *h, const ipx_bam_batch *b) {
+    if (!h || !b) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    int rc = push_complete(h);
+    if (rc) return rc;
+    if (b->n_alignments == 0) return IPX_OK;
+    if ((rc = push_begin_bam(h, b))) return rc;
+    return push_complete(h);
+}
+
+int ipx_push_bam_async(ipx_handle *h, const ipx_bam_batch *b) {
+    if (!h || !b) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    int rc = push_complete(h);              // at most one batch in flight
+    if (rc) return rc;
+    if (b->n_alignments == 0) return IPX_OK;
+    return push_begin_bam(h, b);
 }
 
 int ipx_sync(ipx_handle *h) {

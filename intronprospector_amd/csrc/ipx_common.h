@@ -322,6 +322,14 @@ hipError_t ipx_launch_scan_u32_pair(hipStream_t s, const uint32_t *in1, uint32_t
                                     const uint32_t *in2, uint32_t *out2, uint64_t n2, uint32_t *total2,
                                     uint32_t *block_sums);
 
+// ipx_bam.hip: BAM alignment records (spans = runs of whole records) -> the batch arrays; *err: 0xffffffff, or
+// 1 + the index of the first record that does not parse.  workspace: ipx_bam_workspace_bytes(n)
+size_t ipx_bam_workspace_bytes(uint64_t n);
+hipError_t ipx_launch_bam_decode(hipStream_t s, const uint8_t *bytes, const uint64_t *span_begin, const uint64_t *span_first,
+                                 uint32_t n_spans, uint64_t n, uint64_t n_words, const int32_t *tid_map, uint32_t n_tid_map,
+                                 int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *xs, uint8_t *nh, uint32_t *cigar_off,
+                                 uint32_t *n_cigar, uint32_t *cigar, void *workspace, uint32_t *err);
+
 // ipx_exchange.hip: key-range partitioning of the pending records for the multi-GPU exchange
 hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
                              uint32_t n_samples, unsigned long long *out /* device */);

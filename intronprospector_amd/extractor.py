@@ -109,6 +109,21 @@ class JunctionsExtractor:
         self._check(self.lib.ipx_push_batch(self.h, C.byref(b)))
         self.next_read_index = base_read_index + n
 
+    def push_bam(self, data, span_begin, span_first, n_cigar_words, tid_map=None, base_read_index=None):
+        """data: uint8 array of BAM alignment records (each with its block_size word) back to back; span k is
+        data[span_begin[k]:span_begin[k+1]] and holds records span_first[k] .. span_first[k+1]-1 (ipx_push_bam)."""
+        data = np.ascontiguousarray(data, np.uint8)
+        sb = np.ascontiguousarray(span_begin, np.uint64)
+        sf = np.ascontiguousarray(span_first, np.uint64)
+        n = int(sf[-1])
+        if base_read_index is None:
+            base_read_index = self.next_read_index
+        tm = None if tid_map is None else np.ascontiguousarray(tid_map, np.int32)
+        b = L.BamBatch(n, int(n_cigar_words), base_read_index, data.ctypes.data, len(data), sb.ctypes.data, sf.ctypes.data,
+                       len(sb) - 1, None if tm is None else tm.ctypes.data, 0 if tm is None else len(tm), L.IPX_MEM_HOST)
+        self._check(self.lib.ipx_push_bam(self.h, C.byref(b)))
+        self.next_read_index = base_read_index + n
+
     def push_device(self, n, n_words, ptrs, base_read_index=None):
         """ptrs: device addresses in the order tid,pos,flag,xs,nh,cigar_off,n_cigar,cigar."""
         if base_read_index is None:

@@ -26,6 +26,7 @@ BamFeeder::BamFeeder(BgzfReader &src, const std::string &path, const std::vector
         // cgroup throttled)
         n_workers = v > 0 ? (unsigned)v : (BgzfReader::default_threads() >= 6 ? 2u : 1u);
     }
+    if (n_workers == SPLIT_ONLY) n_workers = 0;
     n_workers = std::min(n_workers, 32u);
     for (unsigned i = 0; i < n_workers; ++i) threads_.emplace_back(&BamFeeder::worker, this);
 }

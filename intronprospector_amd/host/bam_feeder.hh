@@ -28,6 +28,7 @@ namespace ipxhost {
 class BamFeeder {
 public:
     static const int32_t ANY_TARGET = INT32_MIN;
+    static const unsigned SPLIT_ONLY = ~0u;        // n_workers: no parsers, the caller takes the spans as they are
     struct Dest {                                  // the batch the records go to
         int32_t *tid, *pos;
         uint16_t *flag;

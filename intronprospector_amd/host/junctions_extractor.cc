@@ -123,8 +123,24 @@ JunctionsExtractor::~JunctionsExtractor() {
     if (init_thread_.joinable()) init_thread_.join();
     if (h_) ipx_destroy(h_);
     if (g_) ipx_group_destroy(g_);
-    for (HostBatch &b : batch_)
+    for (HostBatch &b : batch_) {
         if (b.mem) ipx_host_free(b.mem);
+        if (b.raw) ipx_host_free(b.raw);
+    }
+}
+
+// (re)allocate a batch's pinned byte buffer for BAM records; what it holds is kept
+void JunctionsExtractor::size_raw(HostBatch &b, size_t cap_bytes) {
+    ensure_device();
+    struct AllocTimer { double &acc; double t0; ~AllocTimer() { acc += now_s() - t0; } } alloc_timer{t_alloc_, now_s()};
+    void *m = nullptr;
+    if (ipx_host_alloc(&m, cap_bytes) != IPX_OK) throw std::runtime_error("out of pinned host memory for the alignment batches");
+    if (b.raw) {
+        memcpy(m, b.raw, b.raw_n);
+        ipx_host_free(b.raw);
+    }
+    b.raw = m;
+    b.raw_cap = cap_bytes;
 }
 
 
@@ -152,6 +168,9 @@ void JunctionsExtractor::throw_last_error(int status) {
     if (g_) ipx_group_last_error(g_, &e);
     else ipx_last_error(h_, &e);
     const std::string msg = e.detail[0] ? std::string(e.detail) : ("ipx status " + std::to_string(status));
+    // a record the device could not parse: what AlnReader::read throws for it
+    if (status == IPX_EINVAL && msg.compare(0, 23, "ipx_push_bam: malformed") == 0)
+        throw std::runtime_error("Error reader BAM record: " + bam_);
     if (status == IPX_EDATA) {
         switch (e.kind) {
             case IPX_DATA_CIGAR: throw std::invalid_argument(msg);      // junctions_extractor.cc:313
@@ -266,6 +285,32 @@ void JunctionsExtractor::flush_batch() {
     }
     if (hb.n == 0) return;
     ensure_device();
+    if (device_parse_) {
+        hb.span_begin.push_back(hb.raw_n);
+        hb.span_first.push_back(hb.n);
+        hb.tid_map = canon_tid_;
+        ipx_bam_batch bb{};
+        bb.n_alignments = hb.n;
+        bb.n_cigar_words = hb.nw;
+        bb.base_read_index = next_read_index_;
+        bb.bytes = (const uint8_t *)hb.raw;
+        bb.n_bytes = hb.raw_n;
+        bb.span_begin = hb.span_begin.data();
+        bb.span_first = hb.span_first.data();
+        bb.n_spans = (uint32_t)(hb.span_begin.size() - 1);
+        bb.tid_map = hb.tid_map.data();
+        bb.n_tid_map = (uint32_t)hb.tid_map.size();
+        bb.memory = IPX_MEM_HOST;
+        const double t0 = timeline_ ? now_s() : 0.0;
+        const int rc = ipx_push_bam_async(h_, &bb);       // completes the other set's push, queues this one
+        if (timeline_) { t_push_ += now_s() - t0; ++n_push_; }
+        next_read_index_ += hb.n;
+        hb.n = hb.nw = hb.raw_n = 0;
+        hb.tables_lent = true;                            // cleared when this set is filled again: the push is over by then
+        cur_ ^= 1;
+        if (rc != IPX_OK) throw_last_error(rc);
+        return;
+    }
     ipx_batch b{};
     b.n_alignments = hb.n;
     b.n_cigar_words = hb.nw;
@@ -287,6 +332,18 @@ void JunctionsExtractor::flush_batch() {
 bool JunctionsExtractor::use_feeder() {
     if (feeder_) return true;
     if (!reader_ || !reader_->bgzf() || pass_through_ || trace_fh_ || aln_pending_) return false;
+    // One GPU: the device can decode the records itself (ipx_push_bam); this thread then only cuts the inflated
+    // blocks into runs of whole records and copies them to pinned memory (0.13 s for the 2.3 GB of a 10 M-record
+    // BAM).  IPX_DEVICE_PARSE=1 asks for it, 0 forbids it; unasked it is used where the feeder below would be:
+    // on the GPU box's 16-CPU share the command line is bound by the twelve inflate threads either way
+    // (1.3-1.4 s with the record-by-record loop, 1.4-1.5 s with this, profiles/r02_cli_timeline.jsonl)
+    const char *dp = getenv("IPX_DEVICE_PARSE");
+    const bool dp_on = dp ? dp[0] != '0' : (!getenv("IPX_PARSE_THREADS") && BgzfReader::usable_cpus() >= 24);
+    if (!g_ && dp_on) {
+        device_parse_ = true;
+        feeder_.reset(new BamFeeder(*reader_->bgzf(), reader_->path(), canon_tid_, BamFeeder::SPLIT_ONLY));
+        return true;
+    }
     // IPX_PARSE_THREADS=N (N >= 1) asks for it, 0 forbids it.  Unasked, it is used where the parsers do not take
     // CPUs away from the inflate pool: on the GPU box's 16-CPU share (12 inflate threads + the loop) a 10 M-record
     // BAM took 1.3-1.4 s without it and 1.3-1.5 s with it -- inflating is 7 of the 8 CPU-seconds either way
@@ -298,7 +355,54 @@ bool JunctionsExtractor::use_feeder() {
     return true;
 }
 
+static const size_t RAW_BATCH_BYTES = (size_t)96 << 20;
+
 bool JunctionsExtractor::feed_target(int32_t target_index, int32_t *other_tid) {
+    while (device_parse_) {
+        HostBatch *b = &batch_[cur_];
+        if (b->tables_lent) {                      // the push that read them completed when the other set was pushed
+            b->span_begin.clear();
+            b->span_first.clear();
+            b->tables_lent = false;
+        }
+        if (!b->raw) {
+            struct stat st;
+            const bool large = stat(reader_->path().c_str(), &st) == 0 && (uint64_t)st.st_size > (16ull << 20);
+            size_raw(*b, large ? RAW_BATCH_BYTES : (size_t)1 << 20);
+        }
+        BamFeeder::Span sp;
+        const double t0 = timeline_ ? now_s() : 0.0;
+        const BamFeeder::Status st = feeder_->next_span(target_index, BATCH_ALIGNMENTS - b->n, (BATCH_ALIGNMENTS * 64) - b->nw, sp, other_tid);
+        const double t1 = timeline_ ? now_s() : 0.0;
+        if (timeline_) t_read_ += t1 - t0;
+        if (st == BamFeeder::SPAN) {
+            const size_t bytes = sp.end - sp.begin;
+            if (b->raw_n + bytes > b->raw_cap) {
+                if (b->n) {                        // this set is full: the run opens the other one
+                    flush_batch();
+                    b = &batch_[cur_];
+                    if (b->tables_lent) { b->span_begin.clear(); b->span_first.clear(); b->tables_lent = false; }
+                }
+                if (!b->raw || bytes > b->raw_cap) {
+                    const size_t want = std::min(RAW_BATCH_BYTES, std::max(b->raw_cap * 8, (size_t)1 << 20));
+                    size_raw(*b, std::max(want, bytes));
+                }
+            }
+            b->span_begin.push_back(b->raw_n);
+            b->span_first.push_back(b->n);
+            memcpy((char *)b->raw + b->raw_n, sp.data->data() + sp.begin, bytes);
+            b->raw_n += bytes;
+            b->n += sp.n_records;
+            b->nw += sp.n_words;
+            table_valid_ = false;
+            if (timeline_) t_queue_ += now_s() - t1;
+        } else if (st == BamFeeder::FULL) {
+            if (b->n == 0) throw std::runtime_error("Error reader BAM record: " + reader_->path() + " (a CIGAR of more than 2^26 operations)");
+            flush_batch();
+        } else {
+            return st == BamFeeder::BOUNDARY;
+        }
+    }
     for (;;) {
         HostBatch *b = &batch_[cur_];
         if (b->cap_aln == 0) {

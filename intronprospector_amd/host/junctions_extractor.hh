@@ -106,6 +106,13 @@ private:
         uint16_t *flag = nullptr;
         uint8_t *xs = nullptr, *nh = nullptr;
         uint32_t *off = nullptr, *nc = nullptr, *cigar = nullptr;
+        // device parse (ipx_push_bam): the records as they lie in the inflated BGZF blocks, and where runs of
+        // whole records begin; the tables stay untouched until the push that borrowed them has completed
+        void *raw = nullptr;
+        size_t raw_cap = 0, raw_n = 0;
+        std::vector<uint64_t> span_begin, span_first;
+        std::vector<int32_t> tid_map;
+        bool tables_lent = false;
     };
     HostBatch batch_[2];
     int cur_ = 0;
@@ -113,6 +120,10 @@ private:
     // thread and parsed straight into the batches by a pool (host/bam_feeder.hh); IPX_PARSE_THREADS=0 keeps
     // the record-by-record loop
     std::unique_ptr<BamFeeder> feeder_;
+    // ... or, on one GPU, only split here and decoded on the device (ipx_push_bam): this thread then copies
+    // whole runs of records into pinned memory and never looks inside them.  IPX_DEVICE_PARSE=0 switches it off
+    bool device_parse_ = false;
+    void size_raw(HostBatch &b, size_t cap_bytes);
     bool use_feeder();
     // records of target_index (BamFeeder::ANY_TARGET: all) from the feeder into the batches;
     // returns false at the end of the input, true at a record of another target (*other_tid)

@@ -15,9 +15,15 @@ T=/tmp/ipx_tl
 mkdir -p $T
 $BIN/ipx_host_check make-bam $N $T/s.bam > /dev/null
 ls -l $T/s.bam | awk '{print "{\"bam_bytes\": " $5 "}"}'
-for run in 1 2 3; do
-  /usr/bin/env bash -c "TIMEFORMAT='{\"wall_s\": %R, \"user_s\": %U, \"sys_s\": %S}'; time IPX_TIMELINE=1 $BIN/intronProspector -c $T/out.tsv -j $T/out.bed $T/s.bam" 2>&1
+# IPX_DEVICE_PARSE=1: the records are decoded on the device (ipx_push_bam); 0: parsed on the reading thread
+for mode in 1 0; do
+  echo "{\"device_parse\": $mode}"
+  for run in 1 2 3; do
+    /usr/bin/env bash -c "TIMEFORMAT='{\"wall_s\": %R, \"user_s\": %U, \"sys_s\": %S}'; time IPX_DEVICE_PARSE=$mode IPX_TIMELINE=1 $BIN/intronProspector -c $T/out$mode.tsv -j $T/out$mode.bed $T/s.bam" 2>&1
+  done
 done
+cmp $T/out1.tsv $T/out0.tsv && cmp $T/out1.bed $T/out0.bed && echo '{"outputs_identical": true}'
+cp $T/out1.tsv $T/out.tsv
 # the BGZF/BAM decode alone, against inflate threads, all on this one file (the r01 series mixed two files)
 for t in 1 2 4 8 12 16; do $BIN/ipx_host_check bench-decode $T/s.bam $t; done
 md5sum $T/out.tsv | awk '{print "{\"calls_md5\": \"" $1 "\"}"}'

@@ -204,7 +204,9 @@ def test_cli_against_the_oracle_on_odd_sam_files(cli, oracle_cli, tmp_path, opts
     assert open(trace, "rb").read() == outs["exp"][2]["trace.tsv"]
     # without the trace the BAM goes through the block-parallel feeder (host/bam_feeder.cc); with IPX_PARSE_THREADS=0
     # through the record-by-record loop: the same bytes either way
-    for k, env in enumerate(({"IPX_PARSE_THREADS": "2"}, {"IPX_PARSE_THREADS": "0"}, {"IPX_PARSE_THREADS": "3", "IPX_DECODE_THREADS": "2"})):
+    # (and by default the device decodes the records itself, ipx_push_bam)
+    for k, env in enumerate(({"IPX_PARSE_THREADS": "2"}, {"IPX_PARSE_THREADS": "0"}, {"IPX_PARSE_THREADS": "3", "IPX_DECODE_THREADS": "2"},
+                             {"IPX_DEVICE_PARSE": "1"}, {"IPX_DEVICE_PARSE": "0"})):
         o = {name: str(tmp_path / ("feed%d.%s" % (k, name))) for name in ("juncs.bed", "introns.bed", "introns.bed6", "introns.tsv")}
         subprocess.run([cli] + opts + ["--junction-bed=" + o["juncs.bed"], "--intron-bed=" + o["introns.bed"],
                                        "--intron-bed6=" + o["introns.bed6"], "--intron-calls=" + o["introns.tsv"], bam],
@@ -225,6 +227,9 @@ def test_cli_against_the_oracle_on_odd_sam_files(cli, oracle_cli, tmp_path, opts
     r = subprocess.run([cli] + opts + ["--intron-calls=" + tsv, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=dict(os.environ, IPX_PARSE_THREADS="2"))
     assert (r.returncode, r.stderr, open(tsv, "rb").read()) == res[1]
+    r = subprocess.run([cli] + opts + ["--intron-calls=" + tsv, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, IPX_DEVICE_PARSE="1"))
+    assert (r.returncode, r.stderr, open(tsv, "rb").read()) == res[1]
 
 
 def test_cli_block_parallel_bam_feeder(cli, tmp_path):
@@ -235,7 +240,8 @@ def test_cli_block_parallel_bam_feeder(cli, tmp_path):
     subprocess.run([os.path.join(os.path.dirname(cli), "ipx_host_check"), "make-bam", "300000", bam], check=True)
     digests = set()
     for mode in ([], ["--unsorted"]):
-        for env, extra in (({"IPX_PARSE_THREADS": "0"}, []), ({"IPX_PARSE_THREADS": "4"}, []), ({"IPX_PARSE_THREADS": "2"}, ["--devices=0,0"])):
+        for env, extra in (({"IPX_PARSE_THREADS": "0"}, []), ({"IPX_PARSE_THREADS": "4"}, []), ({"IPX_PARSE_THREADS": "2"}, ["--devices=0,0"]),
+                           ({"IPX_DEVICE_PARSE": "1"}, []), ({"IPX_DEVICE_PARSE": "1", "IPX_DECODE_THREADS": "3"}, [])):   # the last two: records decoded on the device
             tsv, bed = str(tmp_path / "o.tsv"), str(tmp_path / "o.bed")
             subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed] + mode + extra + [bam], check=True,
                            env=dict(os.environ, **env))
@@ -244,6 +250,56 @@ def test_cli_block_parallel_bam_feeder(cli, tmp_path):
             assert os.path.getsize(tsv) > 10000
     assert len(digests) == 2, digests                   # one digest per mode, whatever the reader
 
+
+
+def test_cli_device_parse_refuses_a_damaged_bam(cli, tmp_path):
+    """a record whose tag section is cut short: "Error reader BAM record" from the device decoder as from the host's"""
+    import gzip
+    import struct
+    import zlib
+    sam = str(tmp_path / "d.sam")
+    with open(sam, "w") as f:
+        f.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:100000\n")
+        for i in range(50):
+            f.write("r%d\t0\tchr1\t%d\t60\t20M100N30M\t*\t0\t0\t%s\t%s\tNH:i:1\n" % (i, 1000 + i, "A" * 50, "I" * 50))
+    bam = str(tmp_path / "d.bam")
+    bamio.sam_to_bam(sam, bam)
+    # inflate all blocks, damage record 20's NH tag type, write the stream back as one BGZF block + EOF block
+    raw = b""
+    data = open(bam, "rb").read()
+    p = 0
+    while p < len(data):
+        bsize = struct.unpack("<H", data[p + 16:p + 18])[0] + 1
+        raw += zlib.decompress(data[p + 18:p + bsize - 8], -15)
+        p += bsize
+    l_text = struct.unpack("<i", raw[4:8])[0]
+    q = 8 + l_text
+    n_ref = struct.unpack("<i", raw[q:q + 4])[0]
+    q += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack("<i", raw[q:q + 4])[0]
+        q += 8 + l_name
+    for _ in range(20):
+        q += 4 + struct.unpack("<i", raw[q:q + 4])[0]
+    bs = struct.unpack("<i", raw[q:q + 4])[0]
+    tag = raw.rfind(b"NHc", q, q + 4 + bs)               # (bamio writes the smallest integer type)
+    assert tag > 0
+    raw = raw[:tag + 2] + b"?" + raw[tag + 3:]
+
+    def block(payload):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(payload) + c.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(payload), len(payload)))
+    bad = str(tmp_path / "bad.bam")
+    with open(bad, "wb") as f:
+        f.write(block(raw) + block(b""))
+    outs = []
+    for env in ({"IPX_DEVICE_PARSE": "1"}, {"IPX_DEVICE_PARSE": "0"}):
+        r = subprocess.run([cli, "-c", str(tmp_path / "x.tsv"), bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, **env))
+        outs.append((r.returncode, r.stderr))
+    assert outs[0] == outs[1] and outs[0][0] == 1 and b"Error reader BAM record" in outs[0][1], outs
 
 
 def test_cli_gzip_outputs(cli, golden, tmp_path):

@@ -109,6 +109,9 @@ def test_bgzf_blocks_inflate_in_parallel_in_file_order(host_check, tmp_path):
         r = subprocess.run([host_check, "dump-aln", bam], stdout=subprocess.PIPE, check=True, env=env)
         outs.append(r.stdout)
     assert all(o == outs[0] for o in outs)
+    # zlib for every block instead of host/fast_inflate.cc: the same records
+    r = subprocess.run([host_check, "dump-aln", bam], stdout=subprocess.PIPE, check=True, env=dict(os.environ, IPX_INFLATE="zlib"))
+    assert r.stdout == outs[0]
     # the benchmark's checksum (what profiles/*_bam_decode_threads.jsonl records) is a function of the file alone
     sums = set()
     for t in ("1", "12"):
@@ -288,3 +291,65 @@ def test_confidence_matches_oracle_on_random_histograms(host_check, tmp_path):
     order = np.lexsort((t["intron_end"], t["intron_start"]))
     for r, i in zip(rows, order):
         assert r.split("\t")[9] == "%.3g" % float(t["confidence"][i])
+
+
+def test_fast_inflate_against_zlib(host_check, tmp_path):
+    """host/fast_inflate.cc, the whole-block DEFLATE decoder behind the BGZF reader: byte-identical with zlib on
+    streams of every block type, level and strategy (stored, fixed, dynamic, flush points, tiny windows, empty
+    input), its CRC-32 equal to zlib's; and on damaged streams it stays inside its buffers and never accepts
+    what zlib inflates differently (ipx_host_check check-inflate)."""
+    import struct
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(77)
+    path = str(tmp_path / "streams.bin")
+    n = 0
+    with open(path, "wb") as out:
+        def put(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, memlevel=8, flushes=0):
+            nonlocal n
+            c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+            comp = b""
+            if flushes and len(data) > flushes:
+                step = len(data) // flushes
+                for k, i in enumerate(range(0, len(data), step)):
+                    comp += c.compress(data[i:i + step]) + c.flush(zlib.Z_FULL_FLUSH if k % 2 else zlib.Z_SYNC_FLUSH)
+            else:
+                comp += c.compress(data)
+            comp += c.flush()
+            out.write(struct.pack("<II", len(comp), len(data)) + comp)
+            n += 1
+
+        def bamlike(k):
+            return b"".join(struct.pack("<iiBBHHHIiii", int(rng.integers(0, 8)), 1000 + 3 * i, 10, 60, 4680, 3, 0, 100, -1, -1, 0) +
+                            b"read%05d\0" % i + struct.pack("<III", 40 << 4, (int(rng.integers(70, 5000)) << 4) | 3, 60 << 4) +
+                            bytes(rng.integers(0, 256, 50, dtype=np.uint8)) + bytes(rng.integers(30, 42, 100, dtype=np.uint8)) + b"NHc\x01"
+                            for i in range(k))
+        fixed = [b"", b"a", b"ab" * 3, b"\0" * 70000, bytes(rng.integers(0, 256, 65280, dtype=np.uint8)),
+                 bytes(rng.integers(0, 4, 65280, dtype=np.uint8)), bamlike(280)[:65280], (b"ACGT" * 20000)[:65280],
+                 b"".join(bytes([int(x)]) * int(k) for x, k in zip(rng.integers(0, 256, 2000), rng.integers(1, 300, 2000)))[:65280],
+                 open(__file__, "rb").read()]
+        for d in fixed:
+            for lvl in (0, 1, 6, 9):
+                put(d, lvl)
+            for st in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                put(d, 6, st)
+            put(d, 6, flushes=7)
+            put(d, 9, memlevel=1)
+            put(d, 1, wbits=-9)
+        for _ in range(300):
+            k, mode = int(rng.integers(0, 70000)), int(rng.integers(0, 4))
+            if mode == 0:
+                d = bytes(rng.integers(0, 256, k, dtype=np.uint8))
+            elif mode == 1:
+                d = bytes(rng.integers(0, int(rng.integers(1, 20)), k, dtype=np.uint8))
+            elif mode == 2:
+                d = bamlike(max(1, k // 230))[:65280]
+            else:
+                base = bytes(rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8))
+                d = (base * (k // len(base) + 1))[:k]
+            put(d, int(rng.integers(0, 10)), [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY][int(rng.integers(0, 4))],
+                memlevel=int(rng.integers(1, 10)))
+    r = subprocess.run([host_check, "check-inflate", path, "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    rep = json.loads(r.stdout)
+    assert rep["streams"] == n and rep["damaged"] >= 8 * (n - 20) and 0 < rep["damaged_still_valid"] < rep["damaged"]

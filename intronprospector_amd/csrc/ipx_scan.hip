@@ -621,404 +621,6 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
     }
 }
 
-constexpr uint32_t LONG2_POOL = 128;         // records per wave pool (4 KB + 4 KB): the ring needs the room
-constexpr uint32_t LONG2_RING = 4;           // chunks of four CIGAR words per lane in the LDS ring (power of two)
-constexpr uint32_t LONG2_SLOW_AT = 40;       // lanes waiting for the op-by-op walk that start it
-
-__global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
-                                                   uint32_t reads_per_wave,
-                                                   const int32_t *__restrict__ a_tid,
-                                                   const int32_t *__restrict__ a_pos,
-                                                   const uint16_t *__restrict__ a_flag,
-                                                   const uint8_t *__restrict__ a_xs,
-                                                   const uint8_t *__restrict__ a_nh,
-                                                   const uint32_t *__restrict__ a_off,
-                                                   const uint32_t *__restrict__ a_nc,
-                                                   const uint32_t *__restrict__ cigar,
-                                                   const uint32_t *__restrict__ tail,
-                                                   const uint32_t *__restrict__ rank_of_tid,
-                                                   uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                   uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
-                                                   uint64_t capacity, Counters *counters) {
-    __shared__ uint4 pool_item[4][LONG2_POOL], pool_pay[4][LONG2_POOL];
-    __shared__ LongStage stage_s[4];
-    __shared__ uint4 ring_s[4][LONG2_RING][64];       // per lane: its next LONG2_RING chunks of four CIGAR words
-    __shared__ uint32_t kb_s[4][6];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint4 *const my_item = pool_item[wave], *const my_pay = pool_pay[wave];
-    LongStage &stage = stage_s[wave];
-    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
-    unsigned long long my_err = IPX_ERRW_NONE;
-
-    auto load4 = [&](uint64_t w) { return load_cigar4(cigar, tail, n_words, w); };
-
-    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
-    uint64_t next = gw * reads_per_wave;          // wave-uniform from here on
-    uint64_t range_end = next + reads_per_wave;
-    if (range_end > n) range_end = n;
-    if (next > n) next = n;
-    uint32_t staged = 0, staged_used = 0;         // alignments in the stage / already handed out
-    uint32_t pool_n = 0;
-    const uint32_t stripe = my_stripe(p);
-
-    auto flush = [&]() {
-        __threadfence_block();
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(append_counter(counters, p, stripe), (unsigned long long)pool_n);
-        base = __shfl(base, 0);
-        for (uint32_t k = lane; k < pool_n; k += 64) {
-            const uint64_t idx = append_index(p, stripe, base + k);
-            if (idx < capacity) {
-                uint4 it = my_item[k];
-                it.w = (uint32_t)idx;
-                items[idx] = it;
-                const uint4 py = my_pay[k];
-                pays[idx] = py;
-                cnts[idx] = IPX_CNT_ONE(py.x & 3u);
-                digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
-                kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
-                kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
-            }
-        }
-        __threadfence_block();
-        pool_n = 0;
-    };
-
-    // ---- per-lane state of the alignment being walked
-    bool active = false, pending = false, redo = false;
-    bool fin = false;                             // the waiting junction is the alignment's last: it sits in the
-                                                  // walk's own registers, not in the snapshot
-    uint64_t my_i = 0;                            // alignment index in the batch
-    uint32_t pos32 = 0, meta = 0, rank = 0;       // meta: strand | cat << 8 | read_rejected << 10
-    uint32_t left = 0;                            // ops not yet applied ( = n_cigar - 4 * cur )
-    uint32_t off0 = 0;                            // first word of the alignment's CIGAR
-    // chunks (four CIGAR words) of the lane's alignment: cur = the one to apply next, landed = chunks that have
-    // reached the LDS ring, fetched = chunks whose load was issued; a load lands two turns after it went out
-    uint32_t cur = 0, landed = 0, fetched = 0, nchunks = 0;
-    uint4 land_a = make_uint4(0, 0, 0, 0), land_b = make_uint4(0, 0, 0, 0);
-    bool in_a = false, in_b = false;              // the landing register holds a chunk of this lane
-    uint4 (*const my_ring)[64] = ring_s[wave];
-    uint32_t idle_turns = 0;                      // turns in a row without a lane on the fast path (wave-uniform)
-#ifdef IPX_LONG2_STATS
-    uint32_t st_turns = 0, st_slow = 0, st_simple = 0, st_wait = 0, st_drain = 0, st_starved = 0, st_active = 0;
-#endif
-    uint32_t state = ST_LIMBO;
-    uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;          // offsets from the alignment's pos
-    uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
-    uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;   // snapshot of a finished junction
-
-    // junction_qc, junctions_extractor.cc:392-397, on a snapshot (offsets are exact and ordered)
-    auto snap_ok = [&]() {
-        const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
-        const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
-        const uint32_t ilen = q_ie - q_is;
-        return !(meta & 0x400u) && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
-               (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
-               (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
-    };
-
-    // QC, pack and store the waiting snapshots of the whole wave (pool -> record arrays when the pool fills up)
-    auto drain = [&]() {
-        const bool pass = pending && snap_ok();
-        const unsigned long long em = ipx_ballot(pass);
-        if (pass) {
-            const uint32_t slot = pool_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-            const unsigned long long ri = base_read_index + my_i;
-            if (ordinal <= IPX_ORD_MAX_ORDINAL) {
-                ReadCtx c;
-                c.pos = 0; c.rank = rank; c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_index = ri;
-                uint4 it, pay;
-                const Rec r{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
-                            (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
-                pack_record_rel(p, c, r, pos32, ordinal, it, pay);
-                my_item[slot] = it;
-                my_pay[slot] = pay;
-            }
-            if (++ordinal > IPX_ORD_MAX_ORDINAL) {
-                const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 1u;
-                my_err = e < my_err ? e : my_err;
-            }
-        }
-        pending = false;
-        fin = false;
-        pool_n += (uint32_t)__popcll(em);
-        if (pool_n > LONG2_POOL - 64) flush();
-    };
-
-    // ---- one op per active lane, written as selects: branches on per-lane conditions cost more than
-    // the few operations they would skip
-    auto step = [&](uint32_t w, bool go) {
-        const bool run = go && active && left != 0;
-        const uint32_t op = w & 0xfu, len = w >> 4;
-        // BAM_CIGAR_STR "MIDNSHP=XB": M0 I1 D2 N3 S4 H5 P6 =7 X8 B9; classes 1 = M/=/X, 2 = N, 4 = I/D, 8 = S/H
-        const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
-        const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
-        const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
-        // I/D :257-275: counters first, then the test
-        lind += (c_id && in_l) ? len : 0u;
-        rind += (c_id && in_r) ? len : 0u;
-        const uint32_t indel2 = cur_indel + len;
-        const bool over = c_id && indel2 > p.max_anchor_indel_size;
-        // the op ends a junction: N :208-229, S/H :306-311, I/D beyond the limit
-        const bool trig = in_r && (c_n || c_sh || over);
-        const bool last = run && left == 1;                             // finish() :278-282 follows this op
-
-        // ---- store waiting snapshots: when one is about to be overwritten or orphaned, or enough wait
-        const unsigned long long pm = ipx_ballot(pending);
-        if (pm && (ipx_ballot(pending && (trig || last || !active)) || __popcll(pm) >= (int)LONG_DRAIN)) drain();
-        s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
-        s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
-        pending = pending || trig;
-
-        // ---- apply the op
-        const uint32_t tpn = tp + len;
-        const bool adv = c_m || c_n || (c_id && op == 2);               // M = X N D move along the reference
-        const bool carry = adv && tpn < tp;
-        const bool bad = run && cls == 0;
-        if (ipx_ballot(carry || bad)) {                                    // rare, wave-uniform
-            if (carry) {                                                 // offsets leave 32 bits: 64-bit re-run
-                if (trig) pending = false;                               // this op's junction comes from the re-run too
-                redo = true;
-            } else if (bad) {                                            // :312-313: the exception ends the read
-                const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
-                const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
-                const unsigned long long e = ((base_read_index + my_i) << IPX_ORD_SHIFT_READ) |
-                                             ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
-                                             (IPX_ERRK_CIGAR << 8) | ch;
-                my_err = e < my_err ? e : my_err;
-            }
-        }
-        const bool n_r = c_n && in_r;                                   // N closes a junction's right anchor ...
-        const bool n_lr = c_n && (in_l || in_r);                        // ... and opens the next intron
-        const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
-        const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
-        const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
-        is = n_lr ? tp : is;
-        as = as2;
-        ie = ie2;
-        ae = c_m ? tpn : ae;
-        uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);               // M from LIMBO zeroes the mismatch counters
-        uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;                    // only: indel counters keep their value
-        lind = n_r ? rind : lind;
-        rind = n_r ? 0u : rind;
-        state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
-        const bool x = c_m && op == 8;                                  // state is LEFT or RIGHT after an M
-        lmm2 += (x && state == ST_LEFT) ? len : 0u;
-        rmm2 += (x && state == ST_RIGHT) ? len : 0u;
-        lmm = lmm2;
-        rmm = rmm2;
-        cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
-        tp = adv ? tpn : tp;
-        // finish(): the alignment's last op leaves a right anchor open (never together with `trig`: an op
-        // that ends a junction does not leave the walk in RIGHT).  The lane stops here, so the junction
-        // stays where it is until the next drain -- which is the next step's, the lane being inactive
-        fin = go ? (last && !carry && !bad && state == ST_RIGHT) : fin;
-        pending = pending || fin;
-        left -= run ? 1u : 0u;
-        active = go ? (run && !last && !carry && !bad) : active;
-    };
-
-    for (;;) {
-        // ---- 64-bit re-run of alignments whose offsets left 32 bits (after their snapshot is stored)
-        if (ipx_ballot(redo && !pending)) {
-            if (redo && !pending) {
-                ReadCtx c;
-                c.pos = (int32_t)pos32; c.flag = 0; c.nhc = 0; c.rank = rank;
-                c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
-                c.read_index = base_read_index + my_i;
-                (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, cnts, digs, kb,
-                                  my_err, append_counter(counters, p, stripe), stripe);
-                redo = false;
-            }
-        }
-        // ---- hand out alignments
-        const unsigned long long idle = ipx_ballot(!active && !pending && !redo);
-        if (idle) {
-            if (next >= range_end) {
-                if (idle == ~0ull) break;
-            } else {
-                if (staged_used == staged) {
-                    // stage the next 64 alignments: process_alignment gate (junctions_extractor.cc:533-536),
-                    // strand, category, and the first chunks of the CIGAR
-                    const uint64_t rem = range_end - next;
-                    staged = rem < 64 ? (uint32_t)rem : 64u;
-                    staged_used = 0;
-                    if (lane < staged) {
-                        const uint64_t i = next + lane;
-                        const int32_t tid = a_tid[i];
-                        uint32_t nc = a_nc[i];
-                        const uint32_t flag = a_flag[i];
-                        const unsigned long long ri = base_read_index + i;
-                        if (nc <= 1 || tid < 0 || (flag & (F_QCFAIL | F_DUP))) nc = 0;
-                        if (nc && (uint32_t)tid >= p.n_targets) {
-                            const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
-                            my_err = e < my_err ? e : my_err;
-                            nc = 0;
-                        }
-                        const uint32_t off = nc ? a_off[i] : 0u;
-                        if (nc && (uint64_t)off + nc > n_words) {            // words outside the batch
-                            const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
-                            my_err = e < my_err ? e : my_err;
-                            nc = 0;
-                        }
-                        stage.nc[lane] = nc;
-                        if (nc) {
-                            const uint32_t nhc = a_nh[i], xs = a_xs[i];
-                            const uint32_t strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(flag, p.strandness)
-                                                                                     : (xs ? xs : (uint32_t)'.');
-                            const uint32_t rej = ((flag & F_SECONDARY) || (p.exclude_multi && nhc == 2)) ? 0x400u : 0u;
-                            stage.pos[lane] = (uint32_t)a_pos[i];
-                            stage.meta[lane] = strand | (read_category(flag, nhc) << 8) | rej;
-                            stage.rank[lane] = p.rank_is_tid ? (uint32_t)tid : rank_of_tid[tid];
-                            stage.off[lane] = off;
-                        }
-                    }
-                    __threadfence_block();
-                }
-                const uint32_t avail = staged - staged_used;
-                if (!active && !pending && !redo) {
-                    const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    if (e < avail) {
-                        const uint32_t k = staged_used + e;
-                        const uint32_t nc = stage.nc[k];
-                        if (nc) {
-                            my_i = next + e;
-                            pos32 = stage.pos[k];
-                            meta = stage.meta[k];
-                            rank = stage.rank[k];
-                            off0 = stage.off[k];
-                            left = nc;
-                            nchunks = (nc + 3u) >> 2;
-                            cur = landed = fetched = 0;
-                            in_a = in_b = false;
-                            state = ST_LIMBO;
-                            tp = as = is = ie = ae = 0;
-                            lmm = rmm = lind = rind = cur_indel = ordinal = 0;
-                            active = true;
-                        }
-                    }
-                }
-                const uint32_t want = (uint32_t)__popcll(idle);
-                const uint32_t took = want < avail ? want : avail;
-                staged_used += took;
-                next += took;
-            }
-        }
-        // ---- two turns: a landing register is written by the load of one turn and emptied into the ring two
-        // turns later (the loop body holds both turns, so each register has a fixed place in the code)
-#pragma unroll
-        for (uint32_t half = 0; half < 2; ++half) {
-            uint4 &land = half ? land_b : land_a;
-            bool &in_land = half ? in_b : in_a;
-            // (1) the chunk this register took up two turns ago goes to its ring slot
-            if (in_land) my_ring[landed & (LONG2_RING - 1)][lane] = land;
-            landed += in_land ? 1u : 0u;
-            // (2) the next chunk, if the ring has room for it (chunks in flight count); lanes that want none
-            // re-read their first words: the load result goes through no select
-            const bool want = active && fetched < nchunks && fetched - cur < LONG2_RING;
-            land = load4(want ? (uint64_t)off0 + 4ull * fetched : (uint64_t)off0);
-            in_land = want;
-            fetched += want ? 1u : 0u;
-            // (3) the chunk to apply, if it has landed
-            const bool have = active && cur < landed;
-            const uint4 q = my_ring[cur & (LONG2_RING - 1)][lane];
-            // FAST PATH.  Nine ops in ten of a long read only lengthen the anchor the walk is in: M / = and I / D
-            // below the indel limit while the state is LEFT or RIGHT (:232-275) -- no junction starts or ends, no
-            // state changes.  A chunk of four such ops is applied here in ~17 instructions per op; anything else
-            // (N, clips, X, an indel run beyond the limit, LIMBO / INTRON, the alignment's last ops, offsets near
-            // 2^32) makes the lane WAIT for the op-by-op walk below, which runs for all waiting lanes at once.
-            uint32_t f_tp = tp, f_ae = ae, f_ind = 0, f_ci = cur_indel, f_max = 0, f_bad = 0;
-            {
-                const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t op = ws[k] & 0xfu, len = ws[k] >> 4;
-                    // bit 0: moves along the reference (M = D), bit 1: indel (I D), bit 2: M / =, bit 3: not for this path
-                    const uint32_t code = (uint32_t)(0x8888888858888325ull >> (op * 4u)) & 0xfu;
-                    f_bad |= code;
-                    const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
-                                   m_m = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2, 1);
-                    f_tp += len & m_adv;
-                    const uint32_t il = len & m_id;
-                    f_ind += il;
-                    f_ci = (f_ci + il) & ~m_m;
-                    f_max = f_ci > f_max ? f_ci : f_max;
-                    f_ae = (f_tp & m_m) | (f_ae & ~m_m);
-                }
-            }
-            const bool simple = have && left > 4u && (state & (ST_LEFT | ST_RIGHT)) != 0u && !(f_bad & 8u) &&
-                                f_max <= p.max_anchor_indel_size && tp < 0x40000000u &&
-                                ((q.x | q.y | q.z | q.w) >> 30) == 0u;
-            const bool waiting = have && !simple;
-            if (simple) {
-                tp = f_tp;
-                ae = f_ae;
-                cur_indel = f_ci;
-                lind += state == ST_LEFT ? f_ind : 0u;
-                rind += state == ST_RIGHT ? f_ind : 0u;
-                left -= 4u;
-                cur += 1u;
-            }
-            // a lane that has finished its alignment keeps its last junction until a drain: do not let it sit idle
-#ifdef IPX_LONG2_STATS
-            st_turns++; st_simple += __popcll(ipx_ballot(simple)); st_active += __popcll(ipx_ballot(active));
-            st_starved += __popcll(ipx_ballot(active && !have));
-            if (ipx_ballot(pending && !active)) st_drain++;
-#endif
-            if (ipx_ballot(pending && !active)) drain();
-            // (4) the op-by-op walk for the lanes that wait: when enough of them do, or when nobody else moves
-            const unsigned long long wm = ipx_ballot(waiting), sm = ipx_ballot(simple);
-            idle_turns = sm ? 0u : idle_turns + 1u;
-            if (wm && ((uint32_t)__popcll(wm) >= LONG2_SLOW_AT || idle_turns >= 3u)) {
-#ifdef IPX_LONG2_STATS
-                st_slow++; st_wait += __popcll(wm);
-#endif
-                step(q.x, waiting);
-                step(q.y, waiting);
-                step(q.z, waiting);
-                step(q.w, waiting);
-                cur += waiting ? 1u : 0u;
-            }
-        }
-    }
-    if (pool_n) flush();
-#ifdef IPX_LONG2_STATS
-    if (lane == 0 && (gw % 997) == 0)
-        printf("wave %llu: turns %u slow %u simple-lanes %u active-lanes %u starved %u waiting-at-slow %u drains %u\n",
-               (unsigned long long)gw, st_turns, st_slow, st_simple, st_active, st_starved, st_wait, st_drain);
-#endif
-
-    unsigned long long e = my_err;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(e, d);
-        e = o < e ? o : e;
-    }
-    if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
-
-    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-            const uint32_t o = __shfl_xor(v[k], dlt);
-            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
-        }
-        if (lane == 0) kb_s[wave][k] = v[k];
-    }
-    __syncthreads();
-    if (t < 6) {
-        const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
-        if (t < 3) {
-            const uint32_t o = x0 | x1 | x2 | x3;
-            if (o) atomicOr(&counters->key_or[t], o);
-        } else {
-            const uint32_t a = x0 & x1 & x2 & x3;
-            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
-        }
-    }
-}
-
 // ---- long CIGARs, third formulation: plain ops at a few instructions each, events on a fixed beat ----
 // Nineteen ops in twenty of a long read only lengthen the anchor the walk is in (M = X, and I / D below the
 // indel limit, while the state is LEFT or RIGHT; junctions_extractor.cc:232-275): they move tp / ae and add to
@@ -1027,7 +629,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long2(ScanParams p, uint64_t n,
 // clip: the op that opens an anchor, ~25 instructions), and LONG3_FAST "plain" steps (~30 instructions: no state,
 // no snapshot, no drain).  A lane that meets anything else in a plain step (N, a clip, an indel run over the
 // limit, its alignment's last op) stands still until the next turn's full step -- a few steps' wait once per
-// junction, where k_scan_long2 let it wait for 40 other lanes.
+// junction (an earlier two-speed kernel let it wait for 40 other lanes and lost).
 // Lanes advance at their own pace, so the CIGAR words go through a per-lane ring in LDS (32 words a lane, word-
 // major: no bank conflicts; row = the word's index in the CIGAR array mod 32, so the ring holds two ALIGNED 64-byte
 // pieces of the array).  A lane asks for its next piece -- four 16-byte loads issued back to back -- as soon as
@@ -2393,7 +1995,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         }();
         const char *lv = getenv("IPX_LONG");
         // k_scan_long3 reads aligned 64-byte pieces of the CIGAR array and counts its words in 32 bits
-        const bool v3 = !(lv && (lv[0] == '1' || lv[0] == '2')) && ((uintptr_t)b.cigar & 15u) == 0 && b.n_cigar_words < (1ull << 31);
+        const bool v3 = !(lv && lv[0] == '1') && ((uintptr_t)b.cigar & 15u) == 0 && b.n_cigar_words < (1ull << 31);
         const uint64_t max_waves = 256ull * 4 * (v3 ? 3 : 4);      // all resident at once (128 VGPRs: 4 waves per SIMD; k_scan_long3: 3, by its LDS)
         uint64_t per_wave = ipx_div_up(b.n_alignments, max_waves);
         if (per_wave < min_range) per_wave = min_range;
@@ -2401,22 +2003,17 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         if (per_wave < 256) per_wave = (per_wave + 63) / 64 * 64;
         const uint64_t waves = ipx_div_up(b.n_alignments, per_wave);
         p.n_stripes = (waves >= 256 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
-        // IPX_LONG=2: the two-speed kernel k_scan_long2 (chunks of four plain ops on a fast path, lanes that meet
-        // anything else wait for a common op-by-op turn).  Exact (tests run both) but slower on the ONT-style
-        // workload, 6.5 against 5.1 ms at 2 M alignments: a sixth of the chunks need the slow turn, so it runs every
-        // five or six fast turns at 60 % of the lanes, and a fast turn costs ~280 instructions, not the ~100 planned
+        // IPX_LONG=1: k_scan_long instead of k_scan_long3 (tests run both).  Round 2 also built a two-speed walk
+        // (k_scan_long2: chunks of four plain ops on a fast path, lanes that met anything else waited for 40 others;
+        // exact, 6.5 ms against 5.1 at 2 M alignments) -- DESIGN.md section 4 has the measurement, the history has the code
         const char *lp = getenv("IPX_LONG_PAD");                  // experiment: extra LDS per block = fewer waves per CU
         const uint32_t pad = lp ? (uint32_t)atol(lp) : 0u;
         if (v3)
             hipLaunchKernelGGL(k_scan_long3, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
-        else if (!(lv && lv[0] == '2'))
-            hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
-                               b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
-                               b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
         else
-            hipLaunchKernelGGL(k_scan_long2, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
+            hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
     }

@@ -1,6 +1,6 @@
-"""Turn statistics of k_scan_long2 (IPX_LONG=2) from a build with -DIPX_LONG2_STATS
-(IPX_LIB_PATH=profiles/microbench/libipx_stats.so): every 997th wave prints how many turns it took, how many
-of them ran the op-by-op walk, and how many lanes were on the fast path / waiting / without data."""
+"""Turn statistics of k_scan_long3 from a build with -DIPX_LONG3_STATS (IPX_LIB_PATH=profiles/microbench/libipx_stats.so):
+every 997th wave prints how many turns it took and how many lane-steps of each kind applied an op (plain steps, the
+full step, the anchor-opening step), how many lanes were active and how many had no CIGAR words in their ring."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -48,8 +48,9 @@ class ShardError:
         raise IpxError(self.status or e.status or L.IPX_EDEVICE, e)
 
 
-def _all_gather_var(t, group=None, local_error=None):
-    """all_gather of 1-D/2-D tensors whose first dimension differs per rank.
+def _all_gather_var(t, group=None, local_error=None, pad_value=0, stacked=False):
+    """all_gather of 1-D/2-D tensors whose first dimension differs per rank.  stacked: return the ranks'
+    arrays as ONE tensor [world, longest, ...] whose rows are filled up with pad_value, and the lengths.
 
     local_error (a ShardError or None on EVERY rank that passes the argument): the ranks' sizes travel
     with the ranks' error orders; if some rank has an error, every rank raises the one that comes first
@@ -68,8 +69,12 @@ def _all_gather_var(t, group=None, local_error=None):
         _raise_earliest([(r[1] << 32) | r[2] for r in rows], local_error, group, t.device)
     sizes = [r[0] for r in rows]
     m = max(max(sizes), 1)
-    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad = torch.full((m,) + tuple(t.shape[1:]), pad_value, dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
+    if stacked:
+        out = torch.empty((world,) + tuple(pad.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather(list(out.unbind(0)), pad, group=group)
+        return out, sizes
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return [b[:s] for b, s in zip(bufs, sizes)]
@@ -372,11 +377,11 @@ class RecordExchanger:
         co_sorted = torch.empty_like(co)
         co_sorted[lij.to(torch.int64)] = co
         co_c = self._to_comm(co)
-        parts = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError())
-        ijunc = torch.zeros(n, dtype=torch.int64, device=co_c.device)
-        for part in parts:
-            if part.numel():
-                ijunc += torch.searchsorted(part, co_c)
+        # (rows filled up with the largest order: they stay sorted and the filling counts for nobody; one
+        # batched search instead of one per rank)
+        parts, _ = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError(),
+                                   pad_value=torch.iinfo(torch.int64).max, stacked=True)
+        ijunc = torch.searchsorted(parts, co_c.unsqueeze(0).expand(parts.shape[0], -1).contiguous()).sum(dim=0)
         t0 = self._lap("global_ijunc", t0)
         self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
         return table, ijunc

@@ -221,6 +221,18 @@ void JunctionsExtractor::close() {
         pass_through_.reset();
     }
     feeder_.reset();
+    if (device_parse_) {
+        // the next input may be SAM text, read record by record into the other kind of batch: nothing of this kind
+        // stays behind (an exception may have left a batch half filled; a push still in flight reads the span tables)
+        if (h_) (void)ipx_sync(h_);
+        for (HostBatch &b : batch_) {
+            b.n = b.nw = b.raw_n = 0;
+            b.span_begin.clear();
+            b.span_first.clear();
+            b.tables_lent = false;
+        }
+        device_parse_ = false;
+    }
     reader_.reset();
     previous_target_ = -1;
     aln_pending_ = false;

@@ -252,6 +252,20 @@ def test_cli_block_parallel_bam_feeder(cli, tmp_path):
 
 
 
+def test_cli_device_parse_then_sam_input(cli, golden, tmp_path):
+    """two inputs into one table: a BAM whose records the device decodes, then SAM text read record by record"""
+    sam = os.path.join(golden, "input", "test_basic.sam")
+    bam = str(tmp_path / "first.bam")
+    bamio.sam_to_bam(os.path.join(golden, "input", "test_multi.sam"), bam)
+    outs = []
+    for mode in ("1", "0"):
+        tsv = str(tmp_path / ("two%s.tsv" % mode))
+        subprocess.run([cli, "--min-confidence-score=0.0", "--intron-calls=" + tsv, bam, sam], check=True,
+                       env=dict(os.environ, IPX_DEVICE_PARSE=mode))
+        outs.append(open(tsv, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 500
+
+
 def test_cli_device_parse_refuses_a_damaged_bam(cli, tmp_path):
     """a record whose tag section is cut short: "Error reader BAM record" from the device decoder as from the host's"""
     import gzip

@@ -1,11 +1,13 @@
 """Differential fuzzing of the device path against the oracle: random batches (synthetic short / long reads,
 structure-free CIGARs of several length ranges, mixtures, random order), random parameters, random number of
-pushes.  Prints one line per failure and a summary.  Run on a GPU box: python profiles/fuzz_campaign.py [N] [seed0]"""
+pushes.  Prints one line per failure and a summary.  Run on a GPU box: python profiles/fuzz_campaign.py [N] [seed0]
+IPX_FUZZ_BAM=1: pushes of up to 12 000 alignments go in as BAM records (ipx_push_bam) instead of the SoA."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers
+import bam_encode
 import intronprospector_amd as ipa
 from intronprospector_amd import synth
 from oracle_binding import Oracle, OracleError
@@ -65,6 +67,7 @@ def make(rng):
 
 
 def main():
+    as_bam = os.environ.get("IPX_FUZZ_BAM") == "1"
     n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     bad = 0
@@ -86,8 +89,14 @@ def main():
         ex = ipa.JunctionsExtractor(targets=names, genome=gen2, **params)
         n = len(batch["tid"])
         cuts = np.linspace(0, n, n_push + 1).astype(int)
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            ex.push(synth.slice_batch(batch, int(a), int(b)))
+        for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            part = synth.slice_batch(batch, int(a), int(b))
+            if as_bam and 0 < b - a <= 12000:
+                # the same alignments as BAM records, decoded on the device (ipx_push_bam); tests/bam_encode.py
+                data, sb, sf, nw = bam_encode.records(part, seed0 + it + 7919 * k)
+                ex.push_bam(data, sb, sf, nw)
+            else:
+                ex.push(part)
         dev = ex.get_junctions()
         ex.close()
         ora = Oracle(targets=names, genome_fasta=fasta, **params)

@@ -1003,7 +1003,11 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             layout(tmp2, outa2);
         }
         const GenomeDev g = genome_dev(h);
-        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->key, rb, g, sj_filter,
+        // no record stands for several (nothing was combined, nothing adopted with counts): the reduce takes a
+        // record's count from its category bits and leaves the count words alone -- one random 128-byte line per
+        // record less (40 M long-read records: the step 7.51 -> 7.35 ms)
+        const uint32_t *cnts_or_null = h->n_raw == h->n_records ? nullptr : h->cnts.as<uint32_t>();
+        HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), cnts_or_null, h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));
         if ((rc = read_back(h, small, rb.totals, 8, h->counters.p, sizeof(Counters) / 4))) return rc;

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
         if (h.ok) {
             const uint4 p = pays[h.it.w];
             // reads per category this record stands for (one, unless the scan combined a tile's copies of it)
-            const uint32_t cw = (MODE != 1) ? cnts[h.it.w] : 0u;
+            // (cnts == nullptr: no record of this table was combined, the word is IPX_CNT_ONE of the category)
+            const uint32_t cw = (MODE != 1) ? (cnts ? cnts[h.it.w] : IPX_CNT_ONE(p.x & 3u)) : 0u;
             const unsigned long long ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
             bool cnt_it = true;
             if (MODE == 1) {

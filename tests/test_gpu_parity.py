@@ -561,6 +561,34 @@ def test_both_long_scan_kernels_match_oracle(max_indel, which, monkeypatch):
     helpers.compare_tables(dev, ora)
 
 
+def test_long_reads_in_device_memory_with_an_unaligned_cigar_array():
+    """k_scan_long3 reads the CIGAR array in aligned 16-byte pieces; an array that starts elsewhere goes to
+    k_scan_long (ipx_launch_scan's fallback) -- both through device-resident batches, against the oracle"""
+    import torch
+    from intronprospector_amd import synth
+    batch, names, _ = synth.long_reads(600, seed=91, n_targets=2, target_len=9_000_000, n_transcripts=30)
+    ora = Oracle(targets=names, max_anchor_indel_size=36)
+    ora.process(batch)
+    want = ora.table()
+    ora.close()
+    dev = torch.device("cuda:0")
+    n, nw = len(batch["tid"]), len(batch["cigar"])
+    for shift in (0, 1, 3):                                 # words in front of the array: 0 = aligned
+        t = {k: torch.from_numpy(np.ascontiguousarray(batch[k], dt)).to(dev) for k, dt in (
+            ("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("xs", np.uint8), ("nh", np.uint8),
+            ("cigar_off", np.uint32), ("n_cigar", np.uint32))}
+        cig = torch.zeros(nw + 8, dtype=torch.int32, device=dev)
+        cig[shift:shift + nw] = torch.from_numpy(batch["cigar"].astype(np.uint32).view(np.int32)).to(dev)
+        assert cig.data_ptr() % 16 == 0
+        ptrs = [t[k].data_ptr() for k in ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar")] + [cig.data_ptr() + 4 * shift]
+        ex = _extractor(targets=names, max_anchor_indel_size=36)
+        ex.push_device(n, nw, ptrs)
+        got = ex.get_junctions()
+        ex.close()
+        assert "error" not in got
+        helpers.compare_tables(got, want)
+
+
 def test_combiner_on_and_off_give_the_same_table(monkeypatch):
     """IPX_COMBINE=0: every junction record reaches the sort on its own; the table must not notice"""
     import hashlib

@@ -967,15 +967,25 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
         // op (finish() follows it), and only while the turn's ops cannot carry out of 32 bits (lengths are 28 bits)
         const uint32_t lim1 = (active && tp < 0x40000000u) ? (have_w < end_w - 1u ? have_w : end_w - 1u) : 0u;
         // ---- (4) the op after an N (or after a clip, or the alignment's first): M = X from INTRON opens the right
-        // anchor, from LIMBO the left one (:232-255) -- k_scan_long's step for exactly this case
+        // anchor, from LIMBO the left one (:232-255) -- k_scan_long's step for exactly this case.  Lanes that are in
+        // LEFT / RIGHT (three in four: they did not stop) take a plain op in the same step
+        uint32_t ind_acc = 0, mm_acc = 0;                           // what the plain ops add to the current side's counters
+        // bit 0: moves along the reference (M = X D), bit 1: indel (I D), bit 2: M = X, bit 3: X; 0: not a plain op
+        constexpr unsigned long long PLAIN_CODES = 0x0000000D50000325ull;
         {
             const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
             const uint32_t op = w & 0xfu, len = w >> 4;
-            const uint32_t code = (uint32_t)(0x0000000D50000325ull >> (op * 4u));
-            const bool ok = cw < lim1 && (code & 4u) != 0u && (state & (ST_LIMBO | ST_INTRON)) != 0u;
-            if (ok) {
+            const uint32_t code = (uint32_t)(PLAIN_CODES >> (op * 4u));
+            const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
+                           m_m = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
+            const bool may = cw < lim1 && (code & 0xfu) != 0u;
+            const bool ok_e = may && m_m != 0u && (state & (ST_LIMBO | ST_INTRON)) != 0u;
+            const uint32_t il = len & m_id;
+            const uint32_t ci = (cur_indel + il) & ~m_m;
+            const bool ok_p = may && (state & (ST_LEFT | ST_RIGHT)) != 0u && ci <= p.max_anchor_indel_size;
+            if (ok_e) {
                 const bool from_limbo = state == ST_LIMBO;
-                const uint32_t xl = len & (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
+                const uint32_t xl = len & m_x;
                 as = from_limbo ? tp : as;
                 ie = from_limbo ? ie : tp;
                 lmm = from_limbo ? xl : lmm;                            // M from LIMBO zeroes the mismatch counters only
@@ -986,8 +996,16 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
                 cur_indel = 0;
                 cw += 1u;
             }
+            if (ok_p) {
+                tp += len & m_adv;
+                ae = (tp & m_m) | (ae & ~m_m);
+                cur_indel = ci;
+                ind_acc = il;
+                mm_acc = len & m_x;
+                cw += 1u;
+            }
 #ifdef IPX_LONG3_STATS
-            st_entry += __popcll(ipx_ballot(ok));
+            st_entry += __popcll(ipx_ballot(ok_e)); st_plain += __popcll(ipx_ballot(ok_p));
 #endif
         }
         // ---- (5) plain steps: only from LEFT / RIGHT, which no plain op leaves
@@ -995,13 +1013,11 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
             const bool lr = (state & (ST_LEFT | ST_RIGHT)) != 0u;
             const uint32_t lim = lr ? lim1 : 0u;
             const uint32_t m_l = state == ST_LEFT ? ~0u : 0u;
-            uint32_t ind_acc = 0, mm_acc = 0;
 #pragma unroll
             for (uint32_t k = 0; k < LONG3_FAST; ++k) {
                 const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
                 const uint32_t op = w & 0xfu, len = w >> 4;
-                // bit 0: moves along the reference (M = X D), bit 1: indel (I D), bit 2: M = X, bit 3: X; 0: not a plain op
-                const uint32_t code = (uint32_t)(0x0000000D50000325ull >> (op * 4u));
+                const uint32_t code = (uint32_t)(PLAIN_CODES >> (op * 4u));
                 const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
                                m_m = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
                 const uint32_t tpn = tp + (len & m_adv);

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch            # before libipx.so: the HIP runtime torch brings along must be the one the process keeps
 
 from tests import helpers
 from tests.oracle_binding import Oracle, OracleError

@@ -625,11 +625,12 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
 // Nineteen ops in twenty of a long read only lengthen the anchor the walk is in (M = X, and I / D below the
 // indel limit, while the state is LEFT or RIGHT; junctions_extractor.cc:232-275): they move tp / ae and add to
 // one counter.  k_scan_long pays the whole state machine (~90 vector instructions) for each of them.  Here a
-// TURN of the wave is one step of the full state machine, one step that knows only the M after an N (or after a
-// clip: the op that opens an anchor, ~25 instructions), and LONG3_FAST "plain" steps (~30 instructions: no state,
-// no snapshot, no drain).  A lane that meets anything else in a plain step (N, a clip, an indel run over the
-// limit, its alignment's last op) stands still until the next turn's full step -- a few steps' wait once per
-// junction (an earlier two-speed kernel let it wait for 40 other lanes and lost).
+// TURN of the wave is one step of the full state machine, one step that knows the M after an N (or after a clip:
+// the op that opens an anchor, ~25 instructions; lanes that are inside an anchor take a plain op in it), and
+// LONG3_FAST "plain" steps (~30 instructions: no state, no snapshot, no drain).  A lane that meets anything else in
+// a plain step (N, a clip, an indel run over the limit, its alignment's last op) stands still until the next
+// turn's full step -- a few steps' wait once per junction (an earlier two-speed kernel let it wait for 40 other
+// lanes and lost).
 // Lanes advance at their own pace, so the CIGAR words go through a per-lane ring in LDS (32 words a lane, word-
 // major: no bank conflicts; row = the word's index in the CIGAR array mod 32, so the ring holds two ALIGNED 64-byte
 // pieces of the array).  A lane asks for its next piece -- four 16-byte loads issued back to back -- as soon as

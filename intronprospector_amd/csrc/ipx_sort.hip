@@ -312,6 +312,24 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *to
     return off + incl - v;
 }
 
+// sixteen consecutive elements of in[0, n) from `base` on (zeros beyond the end).  All sixteen loads go out before the
+// first is waited for: written as `(base + k < n) ? in[base + k] : 0` per element the compiler keeps every load behind
+// its own branch and the sixteen round trips to memory follow one another (k_scan_small took 12.9 us for 2 x 8 k
+// elements that way, 9.1 us now)
+__device__ __forceinline__ void load16(const uint32_t *__restrict__ in, uint64_t base, uint64_t n, uint32_t (&v)[16]) {
+    if (base + 16 <= n) {
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) v[k] = in[base + k];
+    } else {
+        const uint64_t last = n ? n - 1 : 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t x = (base < n) ? in[base + k < n ? base + k : last] : 0u;      // (a lane wholly beyond the end loads nothing)
+            v[k] = (base + k < n) ? x : 0u;
+        }
+    }
+}
+
 // One launch serves one or two independent arrays (blocks [0, a.m) work on job a, the rest on job b): the
 // scans of a step are small and latency-bound, so two arrays in three launches instead of six.
 struct ScanJob {
@@ -328,10 +346,11 @@ __global__ __launch_bounds__(256) void k_scan_sums(ScanJob a, ScanJob b) {
     const ScanJob &j = first ? a : b;
     const uint32_t blk = first ? blockIdx.x : blockIdx.x - a.m;
     const uint64_t base = (uint64_t)blk * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+    uint32_t v[16];
+    load16(j.in, base, j.n, v);
     uint32_t s = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k)
-        if (base + k < j.n) s += j.in[base + k];
+    for (uint32_t k = 0; k < 16; ++k) s += v[k];
     uint32_t tot;
     (void)block_excl_scan_256(s, &tot);
     if (threadIdx.x == 0) j.sums[blk] = tot;
@@ -359,12 +378,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(ScanJob a, ScanJob b) {
     const uint32_t blk = first ? blockIdx.x : blockIdx.x - a.m;
     const uint64_t base = (uint64_t)blk * SCAN_TILE + (uint64_t)threadIdx.x * 16;
     uint32_t v[16];
+    load16(j.in, base, j.n, v);
     uint32_t s = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
-        v[k] = (base + k < j.n) ? j.in[base + k] : 0;
-        s += v[k];
-    }
+    for (uint32_t k = 0; k < 16; ++k) s += v[k];
     uint32_t tot;
     uint32_t ex = block_excl_scan_256(s, &tot) + j.sums[blk];
 #pragma unroll
@@ -386,11 +403,9 @@ __global__ __launch_bounds__(1024) void k_scan_small(ScanJob a, ScanJob b) {
     for (uint32_t j = 0; j < 2; ++j) {
         const ScanJob &job = j ? b : a;
         const uint64_t base = (uint64_t)t * 16;
+        load16(job.in, base, job.n, v[j]);
 #pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) {
-            v[j][k] = (base + k < job.n) ? job.in[base + k] : 0u;
-            s[j] += v[j][k];
-        }
+        for (uint32_t k = 0; k < 16; ++k) s[j] += v[j][k];
     }
     uint32_t incl[2] = {s[0], s[1]};
 #pragma unroll

@@ -562,6 +562,40 @@ def test_both_long_scan_kernels_match_oracle(max_indel, which, monkeypatch):
     helpers.compare_tables(dev, ora)
 
 
+def test_very_long_and_very_short_cigars_side_by_side():
+    """a wave of the long-read kernel whose lanes hold CIGARs of 2 to 300 000 operations: lanes finish and take new
+    alignments while others are hundreds of turns into theirs; ring refills at every alignment of the array"""
+    rng = np.random.default_rng(97)
+    M, I, D, N, S, EQ, X = 0, 1, 2, 3, 4, 7, 8
+    reads = []
+    for n_ops in [300_000, 2, 3, 70_001, 5, 17, 33, 64, 65, 4, 120_000] + [int(x) for x in rng.integers(2, 400, 120)]:
+        ops = []
+        for k in range(n_ops):
+            r = rng.random()
+            if k % 2 == 0:
+                ops.append((int(rng.integers(1, 60)) << 4) | (M if r < 0.8 else (EQ if r < 0.9 else X)))
+            elif r < 0.05:
+                ops.append((int(rng.integers(20, 3000)) << 4) | N)
+            elif r < 0.07:
+                ops.append((int(rng.integers(1, 80)) << 4) | (I if r < 0.06 else D))      # some beyond the indel limit
+            else:
+                ops.append((int(rng.integers(1, 4)) << 4) | (I if r < 0.5 else D))
+        if rng.random() < 0.5:
+            ops[0] = (7 << 4) | S
+        reads.append(ops)
+    nc = np.array([len(r) for r in reads], np.uint32)
+    off = np.zeros(len(reads), np.uint32)
+    off[1:] = np.cumsum(nc[:-1])
+    batch = {"tid": np.zeros(len(reads), np.int32), "pos": np.sort(rng.integers(0, 1000, len(reads))).astype(np.int32),
+             "flag": rng.choice(np.array([0, 16, 256], np.uint16), len(reads)), "xs": np.zeros(len(reads), np.uint8),
+             "nh": np.ones(len(reads), np.uint8), "cigar_off": off, "n_cigar": nc,
+             "cigar": np.concatenate([np.array(r, np.uint32) for r in reads])}
+    for max_indel in (3, 36):
+        dev, ora, err = _run_both(batch, ["chr1"], {"max_anchor_indel_size": max_indel, "min_anchor_length": 4})
+        assert err is None
+        helpers.compare_tables(dev, ora)
+
+
 def test_long_reads_in_device_memory_with_an_unaligned_cigar_array():
     """k_scan_long3 reads the CIGAR array in aligned 16-byte pieces; an array that starts elsewhere goes to
     k_scan_long (ipx_launch_scan's fallback) -- both through device-resident batches, against the oracle"""

@@ -264,7 +264,9 @@ struct HeadOut {
     KeyLayout kl;
 };
 
-template <int MODE>
+// HAS_CNTS false: no record of the table stands for several (nothing combined, nothing adopted with counts), the count
+// word is IPX_CNT_ONE of the record's category and cnts is not read: one random 128-byte line per record less
+template <int MODE, bool HAS_CNTS>
 __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
                                                 const uint4 *__restrict__ pays,
                                                 const uint32_t *__restrict__ cnts,
@@ -322,8 +324,7 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
         if (h.ok) {
             const uint4 p = pays[h.it.w];
             // reads per category this record stands for (one, unless the scan combined a tile's copies of it)
-            // (cnts == nullptr: no record of this table was combined, the word is IPX_CNT_ONE of the category)
-            const uint32_t cw = (MODE != 1) ? (cnts ? cnts[h.it.w] : IPX_CNT_ONE(p.x & 3u)) : 0u;
+            const uint32_t cw = (MODE != 1) ? (HAS_CNTS ? cnts[h.it.w] : IPX_CNT_ONE(p.x & 3u)) : 0u;
             const unsigned long long ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
             bool cnt_it = true;
             if (MODE == 1) {
@@ -704,15 +705,23 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     const bool filter_active = genome.seq_of_rank != nullptr && sj_filter == IPX_SJ_CANON;
     if (!filter_active) {
         ipx_prof_pre(s, IPXK_PHASE_B);
-        hipLaunchKernelGGL(k_reduce<0>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
-                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters, ho);
+        if (cnts)
+            hipLaunchKernelGGL((k_reduce<0, true>), grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
+                               rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters, ho);
+        else
+            hipLaunchKernelGGL((k_reduce<0, false>), grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
+                               rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, bin_count, counters, ho);
         ipx_prof_mark(s, IPXK_PHASE_B);
     } else {
-        hipLaunchKernelGGL(k_reduce<1>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
+        hipLaunchKernelGGL((k_reduce<1, true>), grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
                            rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
         ipx_prof_mark(s, IPXK_PHASE_A);
-        hipLaunchKernelGGL(k_reduce<2>, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
-                           rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
+        if (cnts)
+            hipLaunchKernelGGL((k_reduce<2, true>), grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
+                               rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
+        else
+            hipLaunchKernelGGL((k_reduce<2, false>), grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, pays, cnts, rb.chunk_j, rb.chunk_b,
+                               rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
         ipx_prof_mark(s, IPXK_PHASE_B);
     }
     hipLaunchKernelGGL(k_finish_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.first, rb.creator,

@@ -254,6 +254,17 @@ typedef struct ipx_bam_batch {
 } ipx_bam_batch;
 int ipx_push_bam(ipx_handle *h, const ipx_bam_batch *batch);
 int ipx_push_bam_async(ipx_handle *h, const ipx_bam_batch *batch);
+
+/* EXPERIMENT (not used by the command line yet): BGZF blocks inflated on the device, one lane per block --
+ * what htslib's bgzf.c does block by block under sam_read1 (junctions_extractor.cc:620-634).  comp[0, n_bytes):
+ * the file's bytes (host memory); block b's raw DEFLATE stream is comp[in_off[b], in_off[b + 1]) (in_off has
+ * n_blocks + 1 entries; the BGZF header and the CRC / ISIZE trailer lie outside), its ISIZE is isize[b] (<= 65536)
+ * and its bytes go to out[out_off[b], out_off[b] + isize[b]) (host memory, out_bytes long).  status[b]: 0, or why
+ * the block did not inflate to exactly isize[b] bytes.  CRCs are not checked.  kernel_ms (or NULL): the kernel alone,
+ * without the copies.  Stateless: allocates and frees what it needs. */
+int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_bytes, const uint64_t *in_off,
+                     const uint32_t *isize, const uint64_t *out_off, uint64_t n_blocks, uint8_t *out,
+                     uint64_t out_bytes, uint32_t *status, float *kernel_ms);
 /* pinned (page-locked) host memory, hipHostMalloc / hipHostFree */
 int ipx_host_alloc(void **out, size_t bytes);
 int ipx_host_free(void *p);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "ipx_group_set_option", "ipx_group_push_batch", "ipx_group_finalize", "ipx_group_clear",
     "ipx_group_last_error", "ipx_group_uses_rccl",
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
-    "ipx_push_bam", "ipx_push_bam_async",
+    "ipx_push_bam", "ipx_push_bam_async", "ipx_bgzf_inflate",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -111,6 +111,7 @@ def load():
     lib.ipx_sync.argtypes = [vp]
     lib.ipx_push_bam.argtypes = [vp, C.POINTER(BamBatch)]
     lib.ipx_push_bam_async.argtypes = [vp, C.POINTER(BamBatch)]
+    lib.ipx_bgzf_inflate.argtypes = [C.c_int32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_float)]
     lib.ipx_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.ipx_host_free.argtypes = [vp]
     lib.ipx_finalize.argtypes = [vp, C.c_int32, C.POINTER(Table)]

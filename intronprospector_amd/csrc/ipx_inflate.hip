@@ -1,0 +1,281 @@
+// ipx_inflate.hip -- BGZF blocks inflated on the device, one lane per block (EXPERIMENT).
+//
+// A BGZF file is tens of thousands of independent DEFLATE streams of at most 64 KiB each (the reference reads its
+// BAM through htslib's bgzf.c, which inflates them one after the other; src/junctions_extractor.cc:620-634 sits on
+// top of that).  Inflating is what bounds the command line (6 of its 7 CPU-seconds on a 10 M-record file), and
+// the blocks are independent, so every lane of the device can take one: a serial decoder per lane, Huffman tables
+// in a private slice of global memory (they stay in L2), no cooperation between lanes.  RFC 1951 throughout:
+//   * codes of up to 10 bits (literal/length) or 8 bits (distance) through a direct table, longer ones through
+//     the canonical count/offset walk bit by bit (rare symbols);
+//   * every loop is bounded by the block's output size or a constant, every index is checked: a damaged stream
+//     ends in a status word, not in a fault or a wave that never finishes.
+// status[b]: 0 = inflated to exactly isize[b] bytes, otherwise an error code (1 bad block type / stored header,
+// 2 bad code lengths, 3 invalid code, 4 distance before the start, 5 output overrun, 6 input overrun, 7 wrong size).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ipx_common.h"
+
+namespace {
+
+constexpr uint32_t LLB = 10, DB = 8;
+constexpr uint32_t LANE_WORDS = 1024;                 // private table space per lane: 4 KiB
+// byte offsets inside a lane's slice
+constexpr uint32_t O_LL = 0, O_D = 2048, O_SLL = 2560, O_SD = 3136, O_LENS = 3200, O_CNT = 3520;   // u16 ll[1024], u16 d[256], u16 sorted_ll[288], u16 sorted_d[32], u8 lens[320], u16 cnt_ll[16], u16 cnt_d[16]
+
+__constant__ uint16_t C_LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t C_LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t C_DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
+                                         4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t C_DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t C_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Bits {
+    const uint8_t *base;          // the whole compressed buffer (4-byte aligned)
+    uint64_t pos, end;            // next byte to fetch / one past the block's last byte
+    uint64_t buf;
+    uint32_t cnt;
+    uint32_t past;                // zero bytes supplied beyond `end`
+    // at least 33 bits (zeros beyond the end)
+    __device__ __forceinline__ void fill() {
+        while (cnt <= 32) {
+            if (pos >= end) {                                           // nothing left: four zero bytes, not a load
+                cnt += 32;
+                past += 4;
+                pos += 4;
+                continue;
+            }
+            // the aligned word around pos, cut to the bytes of this block
+            const uint64_t a = pos & ~3ull;
+            uint32_t w = *reinterpret_cast<const uint32_t *>(base + a);
+            const uint32_t skip = (uint32_t)(pos - a);                  // bytes of the word that lie before pos
+            w >>= 8 * skip;
+            uint32_t have = 4 - skip;                                   // bytes now in w
+            if (pos + have > end) {
+                const uint32_t keep = pos < end ? (uint32_t)(end - pos) : 0u;
+                w &= keep >= 4 ? 0xffffffffu : ((1u << (8 * keep)) - 1u);
+                past += have - keep;
+            }
+            buf |= (uint64_t)w << cnt;
+            cnt += 8 * have;
+            pos += have;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t code, uint32_t len) { return __brev(code) >> (32 - len); }
+
+// direct table (codes of at most `primary` bits) + sorted symbols and counts for the canonical walk; false: the
+// lengths over-subscribe the code space
+__device__ bool build(const uint8_t *lens, uint32_t n_sym, uint32_t primary, uint16_t *tab, uint16_t *sorted, uint16_t *cnt) {
+    for (uint32_t l = 0; l < 16; ++l) cnt[l] = 0;
+    for (uint32_t s = 0; s < n_sym; ++s) cnt[lens[s]]++;
+    cnt[0] = 0;
+    int left = 1;
+    for (uint32_t l = 1; l < 16; ++l) {
+        left <<= 1;
+        left -= (int)cnt[l];
+        if (left < 0) return false;
+    }
+    uint32_t offs[16], next[16];
+    offs[1] = 0;
+    uint32_t code = 0;
+    next[0] = 0;
+    for (uint32_t l = 1; l < 16; ++l) {
+        if (l > 1) offs[l] = offs[l - 1] + cnt[l - 1];
+        code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
+        next[l] = code;
+    }
+    const uint32_t size = 1u << primary;
+    for (uint32_t i = 0; i < size; ++i) tab[i] = 0xffffu;
+    for (uint32_t s = 0; s < n_sym; ++s) {
+        const uint32_t l = lens[s];
+        if (!l) continue;
+        sorted[offs[l]++] = (uint16_t)s;
+        const uint32_t c = next[l]++;
+        if (l <= primary) {
+            const uint32_t r = rev_bits(c, l);
+            const uint16_t e = (uint16_t)(s | (l << 12));
+            for (uint32_t i = r; i < size; i += 1u << l) tab[i] = e;
+        }
+    }
+    return true;
+}
+
+// a symbol: through the direct table, or bit by bit (RFC 1951 3.2.2's canonical order); 0xffffffff: no such code
+__device__ __forceinline__ uint32_t decode(Bits &b, const uint16_t *tab, uint32_t primary, const uint16_t *sorted, const uint16_t *cnt) {
+    const uint32_t e = tab[b.peek(primary)];
+    if (e != 0xffffu) {
+        b.drop(e >> 12);
+        return e & 0x1ffu;
+    }
+    uint32_t code = 0, first = 0, index = 0;
+    uint64_t bits = b.buf;
+    for (uint32_t l = 1; l < 16; ++l) {
+        code |= (uint32_t)(bits & 1u);
+        bits >>= 1;
+        const uint32_t c = cnt[l];
+        if (code - first < c) {
+            b.drop(l);
+            return sorted[index + (code - first)];
+        }
+        index += c;
+        first = (first + c) << 1;
+        code <<= 1;
+    }
+    return 0xffffffffu;
+}
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                                     const uint32_t *__restrict__ isize, const uint64_t *__restrict__ out_off,
+                                                     uint64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tables,
+                                                     uint32_t *__restrict__ status) {
+    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blk >= n_blocks) return;
+    uint8_t *slice = reinterpret_cast<uint8_t *>(tables + blk * LANE_WORDS);
+    uint16_t *ll = reinterpret_cast<uint16_t *>(slice + O_LL), *dt = reinterpret_cast<uint16_t *>(slice + O_D);
+    uint16_t *sll = reinterpret_cast<uint16_t *>(slice + O_SLL), *sd = reinterpret_cast<uint16_t *>(slice + O_SD);
+    uint8_t *lens = slice + O_LENS;
+    uint16_t *cll = reinterpret_cast<uint16_t *>(slice + O_CNT), *cd = cll + 16;
+    Bits b{comp, in_off[blk], in_off[blk + 1], 0, 0, 0};
+    uint8_t *const o = out + out_off[blk];
+    const uint32_t cap = isize[blk];
+    uint32_t n_out = 0, err = 0;
+    for (uint32_t guard = 0; guard < 70000 && !err; ++guard) {            // a block of n bytes has at most n / 1 DEFLATE blocks worth looking at
+        b.fill();
+        const uint32_t final_block = b.take(1), type = b.take(2);
+        if (type == 0) {
+            b.drop(b.cnt & 7u);
+            b.fill();
+            const uint32_t len = b.take(16);
+            b.fill();
+            const uint32_t nlen = b.take(16);
+            if ((len ^ nlen) != 0xffffu) { err = 1; break; }
+            if (n_out + len > cap) { err = 5; break; }
+            for (uint32_t k = 0; k < len; ++k) {
+                b.fill();
+                o[n_out++] = (uint8_t)b.take(8);
+            }
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {
+                for (uint32_t i = 0; i < 144; ++i) lens[i] = 8;
+                for (uint32_t i = 144; i < 256; ++i) lens[i] = 9;
+                for (uint32_t i = 256; i < 280; ++i) lens[i] = 7;
+                for (uint32_t i = 280; i < 288; ++i) lens[i] = 8;
+                (void)build(lens, 288, LLB, ll, sll, cll);
+                for (uint32_t i = 0; i < 32; ++i) lens[i] = 5;
+                (void)build(lens, 32, DB, dt, sd, cd);
+            } else {
+                b.fill();
+                const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
+                if (hlit > 286 || hdist > 30) { err = 2; break; }
+                uint8_t *pre = lens + 300;                               // 19 code-length code lengths, behind the others
+                for (uint32_t i = 0; i < 19; ++i) pre[i] = 0;
+                for (uint32_t i = 0; i < hclen; ++i) {
+                    b.fill();
+                    pre[C_ORDER[i]] = (uint8_t)b.take(3);
+                }
+                // the code-length code: 7 bits at most, through the distance table's space
+                if (!build(pre, 19, 7, dt, sd, cd)) { err = 2; break; }
+                const uint32_t total = hlit + hdist;
+                uint32_t i = 0;
+                while (i < total && !err) {
+                    b.fill();
+                    const uint32_t sym = decode(b, dt, 7, sd, cd);
+                    if (sym > 18) { err = 3; break; }
+                    if (sym < 16) { lens[i++] = (uint8_t)sym; continue; }
+                    uint32_t rep, val = 0;
+                    if (sym == 16) {
+                        if (i == 0) { err = 2; break; }
+                        val = lens[i - 1];
+                        rep = 3 + b.take(2);
+                    } else if (sym == 17) {
+                        rep = 3 + b.take(3);
+                    } else {
+                        rep = 11 + b.take(7);
+                    }
+                    if (i + rep > total) { err = 2; break; }
+                    for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
+                }
+                if (err) break;
+                if (lens[256] == 0) { err = 2; break; }
+                // the distance lengths follow the literal/length ones in lens[]: build that table first, it moves nothing
+                if (!build(lens + hlit, hdist, DB, dt, sd, cd)) { err = 2; break; }
+                if (!build(lens, hlit, LLB, ll, sll, cll)) { err = 2; break; }
+            }
+            // symbols
+            for (uint32_t sguard = 0; sguard < 70000; ++sguard) {        // every symbol but the last writes a byte
+                b.fill();
+                const uint32_t sym = decode(b, ll, LLB, sll, cll);
+                if (sym < 256) {
+                    if (n_out >= cap) { err = 5; break; }
+                    o[n_out++] = (uint8_t)sym;
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym > 285) { err = 3; break; }
+                const uint32_t len = C_LEN_BASE[sym - 257] + b.take(C_LEN_EXTRA[sym - 257]);
+                b.fill();
+                const uint32_t ds = decode(b, dt, DB, sd, cd);
+                if (ds > 29) { err = 3; break; }
+                const uint32_t dist = C_DIST_BASE[ds] + b.take(C_DIST_EXTRA[ds]);
+                if (dist > n_out) { err = 4; break; }
+                if (n_out + len > cap) { err = 5; break; }
+                for (uint32_t k = 0; k < len; ++k, ++n_out) o[n_out] = o[n_out - dist];
+            }
+        } else {
+            err = 1;
+        }
+        if (final_block) break;
+    }
+    if (!err && b.past * 8 > b.cnt) err = 6;                            // bits were taken from beyond the block's end
+    if (!err && n_out != cap) err = 7;
+    status[blk] = err;
+}
+
+}  // namespace
+
+extern "C" int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_bytes, const uint64_t *in_off,
+                                const uint32_t *isize, const uint64_t *out_off, uint64_t n_blocks, uint8_t *out,
+                                uint64_t out_bytes, uint32_t *status, float *kernel_ms) {
+    if (!comp || !in_off || !isize || !out_off || !out || !status || n_blocks == 0) return IPX_EINVAL;
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (in_off[b] > in_off[b + 1] || in_off[b + 1] > n_bytes || isize[b] > 65536 || out_off[b] + isize[b] > out_bytes) return IPX_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return IPX_ENODEVICE;
+    uint8_t *d_comp = nullptr, *d_out = nullptr;
+    uint64_t *d_in_off = nullptr, *d_out_off = nullptr;
+    uint32_t *d_isize = nullptr, *d_tables = nullptr, *d_status = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = IPX_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == IPX_OK) rc = IPX_EDEVICE; return e == hipSuccess; };
+    ok(hipMalloc(&d_comp, n_bytes + 8)) && ok(hipMalloc(&d_out, out_bytes + 8)) && ok(hipMalloc(&d_in_off, 8 * (n_blocks + 1))) &&
+        ok(hipMalloc(&d_out_off, 8 * n_blocks)) && ok(hipMalloc(&d_isize, 4 * n_blocks)) &&
+        ok(hipMalloc(&d_tables, 4ull * LANE_WORDS * n_blocks)) && ok(hipMalloc(&d_status, 4 * n_blocks)) &&
+        ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1));
+    if (rc == IPX_OK) {
+        ok(hipMemcpy(d_comp, comp, n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemset(d_comp + n_bytes, 0, 8));
+        ok(hipMemcpy(d_in_off, in_off, 8 * (n_blocks + 1), hipMemcpyHostToDevice));
+        ok(hipMemcpy(d_out_off, out_off, 8 * n_blocks, hipMemcpyHostToDevice));
+        ok(hipMemcpy(d_isize, isize, 4 * n_blocks, hipMemcpyHostToDevice));
+    }
+    if (rc == IPX_OK) {
+        ok(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(k_bgzf_inflate, dim3((uint32_t)ipx_div_up(n_blocks, 64)), dim3(64), 0, nullptr, d_comp, d_in_off, d_isize,
+                           d_out_off, n_blocks, d_out, d_tables, d_status);
+        ok(hipGetLastError());
+        ok(hipEventRecord(e1, nullptr));
+        ok(hipEventSynchronize(e1));
+        if (rc == IPX_OK && kernel_ms) ok(hipEventElapsedTime(kernel_ms, e0, e1));
+        ok(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+        ok(hipMemcpy(status, d_status, 4 * n_blocks, hipMemcpyDeviceToHost));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_comp); (void)hipFree(d_out); (void)hipFree(d_in_off); (void)hipFree(d_out_off);
+    (void)hipFree(d_isize); (void)hipFree(d_tables); (void)hipFree(d_status);
+    return rc;
+}

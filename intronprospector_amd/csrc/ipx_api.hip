@@ -141,7 +141,7 @@ struct ipx_handle {
     // holds records; an empty handle takes `first_hint`: the window the last sort would have liked
     // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
     DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
-    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws, defer, bam_raw;
+    DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws, defer, bam_raw, bs_ws;
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
     uint32_t *mail_host = nullptr, *mail_dev = nullptr;      // k_publish's mailbox (pinned, host-coherent)
@@ -481,7 +481,7 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->d_rank_seq, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
-                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer, &h->bam_raw})
+                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer, &h->bam_raw, &h->bs_ws})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->mail_host) (void)hipHostFree(h->mail_host);
@@ -935,33 +935,61 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
                 fprintf(stderr, " [%u+%u,%u+%u]", plan.digits[k].lo1, plan.digits[k].w1, plan.digits[k].lo2, plan.digits[k].w2);
             fprintf(stderr, "\n");
         }
+        uint32_t *tot = h->d_small.as<uint32_t>();      // [0] junctions, [1] bins, [2] the bucket sort's overflow flag
+        // Which sort: the bucket sort (ipx_bsort.hip: every record moves three times whatever the key width) from
+        // IPX_BSORT_MIN records on (default 32768; tests force either), the LSD radix sort below that, for keys
+        // without 16 spare bits, and when a leaf of the bucket sort did not fit LDS.  IPX_SORT=lsd: always LSD.
+        const uint64_t bsort_min = [] {                   // read per call: tests switch between runs
+            const char *m = getenv("IPX_SORT");
+            if (m && m[0] == 'l') return ~0ull;
+            const char *e = getenv("IPX_BSORT_MIN");
+            return e ? (uint64_t)atoll(e) : 32768ull;
+        }();
+        bool by_buckets = resort && R >= bsort_min && ipx_bsort_applicable(R, h->key);
+        auto lsd_sort = [&](bool bytes_valid, const SortPlan &pl) -> int {
+            HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
+                                   h->dig_b.as<uint8_t>(), bytes_valid, R, pl, h->sort_ws.p, h->sort_ws.cap));
+            // the records now live (sorted) in one of the two buffers; keep that one as items_a
+            // so that later pushes append to, and later sorts start from, a full copy
+            if (pl.n & 1u) {
+                std::swap(h->items_a, h->items_b);
+                std::swap(h->dig_a, h->dig_b);
+            }
+            return IPX_OK;
+        };
         if (resort) {
             if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
             if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
             if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
-            HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
-                                   h->dig_b.as<uint8_t>(), use_bytes, R, plan, h->sort_ws.p, h->sort_ws.cap));
-            // the records now live (sorted) in one of the two buffers; keep that one as items_a
-            // so that later pushes append to, and later sorts start from, a full copy
-            if (plan.n & 1u) {
-                std::swap(h->items_a, h->items_b);
-                std::swap(h->dig_a, h->dig_b);
+            if (by_buckets) {
+                if ((rc = ensure(h, h->bs_ws, ipx_bsort_workspace_bytes()))) return rc;
+                HIPCHK(ipx_launch_bsort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
+                                        h->dig_b.as<uint8_t>(), R, h->key, vary, h->sort_ws.p, h->sort_ws.cap, h->bs_ws.p, tot + 2));
+            } else {
+                if ((rc = lsd_sort(use_bytes, plan))) return rc;
             }
             // digit-0 bytes of the sorted order (a later re-sort starts with digit 0 again)
             h->digs_stale = true;
         }
-        SortedItems si{h->items_a.as<uint4>(), R};
         uint32_t *chunk_j = h->sort_ws.as<uint32_t>();
         uint32_t *chunk_b = chunk_j + chunks_al;
         uint32_t *sums = chunk_b + chunks_al;
-        uint32_t *tot = h->d_small.as<uint32_t>();
-        if (resort) {
-            HIPCHK(ipx_launch_count_heads(s, si, chunk_j, chunk_b));
-            HIPCHK(ipx_launch_scan_u32_pair(s, chunk_j, chunk_j, chunks, tot + 0, chunk_b, chunk_b, chunks, tot + 1, sums));
+        for (;;) {
+            SortedItems si0{h->items_a.as<uint4>(), R};
+            if (resort) {
+                HIPCHK(ipx_launch_count_heads(s, si0, chunk_j, chunk_b));
+                HIPCHK(ipx_launch_scan_u32_pair(s, chunk_j, chunk_j, chunks, tot + 0, chunk_b, chunk_b, chunks, tot + 1, sums));
+            }
+            if ((rc = read_back(h, small, tot, by_buckets ? 3 : 2))) return rc;
+            h->prof.collect();
+            ipx_prof_mark(s, IPXK_BEGIN);
+            if (!by_buckets || small[2] == 0) break;
+            // a leaf did not fit LDS: the records are all there, keys intact, in some order -> the LSD sort
+            if (getenv("IPX_DEBUG_PLAN")) fprintf(stderr, "ipx: bucket sort overflowed a leaf, sorting %llu records by radix passes\n", (unsigned long long)R);
+            by_buckets = false;
+            if ((rc = lsd_sort(false, ideal))) return rc;
         }
-        if ((rc = read_back(h, small, tot, 2))) return rc;
-        h->prof.collect();
-        ipx_prof_mark(s, IPXK_BEGIN);
+        SortedItems si{h->items_a.as<uint4>(), R};
         J = small[0];
         B = small[1];
 
@@ -1184,7 +1212,8 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
 static const char *const kKernelNames[IPXK_COUNT] = {
     "begin", "k_scan", "k_hist", "k_binscan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
     "k_write_heads", "k_motif", "memset", "k_reduce_a", "k_reduce", "k_finish_junctions", "k_bins",
-    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt", "ijunc_rank_sort"};
+    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt", "ijunc_rank_sort", "k_bs_prep",
+    "k_bs_leaf"};
 
 int ipx_profile(ipx_handle *h, int enable) {
     if (!h) return IPX_EINVAL;

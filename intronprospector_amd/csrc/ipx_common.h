@@ -135,6 +135,9 @@ struct SortPlan {
 // max_bits of them.  first: a window that is to be the first pass whatever varies in it (its digit
 // bytes were written together with the records), or NULL.  The caller checks with
 // ipx_window_is_first() that no varying bit below the window's top lies outside it.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
 static inline SortPlan ipx_plan_sort(const uint32_t vary[3], uint32_t max_bits, const DigitSpec *first) {
     SortPlan plan{};
     uint32_t bit = 0;
@@ -286,7 +289,7 @@ enum IpxKernelId {
     IPXK_SCAN, IPXK_SORT_HIST, IPXK_SORT_SCAN, IPXK_SORT_SKIP, IPXK_SORT_SCATTER,
     IPXK_COUNT_HEADS, IPXK_SCAN_U32, IPXK_WRITE_HEADS, IPXK_MOTIF, IPXK_MEMSET, IPXK_PHASE_A,
     IPXK_PHASE_B, IPXK_FINISH_J, IPXK_BINS, IPXK_EMIT_BINS, IPXK_EMIT_J, IPXK_EMIT_IJUNC,
-    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_RANK_SORT, IPXK_COUNT
+    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_RANK_SORT, IPXK_BS_PREP, IPXK_BS_LEAF, IPXK_COUNT
 };
 void ipx_prof_mark(hipStream_t s, int id);
 // before a launch of class id: opens the interval when that class alone is being timed (ipx_profile_only)
@@ -310,9 +313,20 @@ hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_bat
 size_t ipx_sort_workspace_bytes(uint64_t n);
 // result in buf_b when plan.n is odd, else in buf_a; dig_a/dig_b: digit-byte streams or NULL
 // prof_all: when >= 0, every kernel of this sort is charged to that profiler id
+// after_last: when given, the last pass also writes that digit's bytes next to the items it moves (dig_a for an
+// even number of passes, dig_b for an odd one) -- the bucket sort reads its leaf boundaries from them
 hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b,
                            bool first_bytes_valid, uint64_t n, const SortPlan &plan, void *workspace,
-                           size_t workspace_bytes, int prof_all = -1);
+                           size_t workspace_bytes, int prof_all = -1, const DigitSpec *after_last = nullptr);
+
+// ipx_bsort.hip: the bucket sort (sampled splitters -> two radix passes on a 16-bit leaf id -> every leaf sorted
+// in LDS).  Sorts buf_a in place (buf_b, dig_a, dig_b are scratch).  *overflow (device word) is set when a leaf
+// did not fit LDS: buf_a then holds the records in some order, keys intact, and the caller runs ipx_launch_sort.
+bool ipx_bsort_applicable(uint64_t n, const KeyLayout &kl);
+size_t ipx_bsort_workspace_bytes(void);
+hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b, uint64_t n,
+                            const KeyLayout &kl, const uint32_t vary[3], void *sort_ws, size_t sort_ws_bytes,
+                            void *bs_ws, uint32_t *overflow);
 // in == out allowed; block_sums needs div_up(n,4096)+1 words; total may be NULL
 hipError_t ipx_launch_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint64_t n,
                                uint32_t *block_sums, uint32_t *total);

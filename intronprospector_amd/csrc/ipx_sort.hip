@@ -481,7 +481,7 @@ size_t ipx_sort_workspace_bytes(uint64_t n) {
 // histogram reads the items).
 hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b,
                            bool first_bytes_valid, uint64_t n, const SortPlan &plan, void *workspace,
-                           size_t workspace_bytes, int prof_all) {
+                           size_t workspace_bytes, int prof_all, const DigitSpec *after_last) {
     if (n == 0 || plan.n == 0) return hipSuccess;
     if (ipx_sort_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
     // large inputs (3 M records on: L with 4.05 M gains 1.5 % of its step, hist and bin scan get cheaper): 4096-item
@@ -508,8 +508,8 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     static const uint32_t scatter_nt = [] { const char *e = getenv("IPX_SCATTER_NT"); return e ? (uint32_t)atoi(e) : 512u; }();
     for (uint32_t k = 0; k < plan.n; ++k) {
         const DigitSpec d = plan.digits[k];
-        const bool has_next = k + 1 < plan.n;
-        const DigitSpec next_d = has_next ? plan.digits[k + 1] : DigitSpec{0, 8, 0, 0};
+        const bool has_next = k + 1 < plan.n || after_last != nullptr;
+        const DigitSpec next_d = k + 1 < plan.n ? plan.digits[k + 1] : (after_last ? *after_last : DigitSpec{0, 8, 0, 0});
         const bool from_bytes = bytes && (k > 0 || first_bytes_valid);
 #define IPX_HIST(B, G, T) hipLaunchKernelGGL((k_hist<B, G, T>), dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles)
         if (big) {

@@ -936,14 +936,17 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             fprintf(stderr, "\n");
         }
         uint32_t *tot = h->d_small.as<uint32_t>();      // [0] junctions, [1] bins, [2] the bucket sort's overflow flag
-        // Which sort: the bucket sort (ipx_bsort.hip: every record moves three times whatever the key width) from
-        // IPX_BSORT_MIN records on (default 32768; tests force either), the LSD radix sort below that, for keys
-        // without 16 spare bits, and when a leaf of the bucket sort did not fit LDS.  IPX_SORT=lsd: always LSD.
+        // Which sort: the bucket sort (ipx_bsort.hip: every record moves through HBM three times whatever the key
+        // width) from IPX_BSORT_MIN records on, the LSD radix sort below that, for keys without 16 spare bits, and
+        // when a leaf of the bucket sort did not fit LDS.  Default 4 M records: measured on one MI355X the two are
+        // level at 2 M records (S: 0.720 / 0.718 ms per step, fourteen launches against twenty-four) and the bucket
+        // sort wins where the radix passes are bandwidth-bound (L, 40 M records: 7.22 / 7.37 ms).  IPX_SORT=lsd:
+        // always LSD; tests force either.
         const uint64_t bsort_min = [] {                   // read per call: tests switch between runs
             const char *m = getenv("IPX_SORT");
             if (m && m[0] == 'l') return ~0ull;
             const char *e = getenv("IPX_BSORT_MIN");
-            return e ? (uint64_t)atoll(e) : 32768ull;
+            return e ? (uint64_t)atoll(e) : (4ull << 20);
         }();
         bool by_buckets = resort && R >= bsort_min && ipx_bsort_applicable(R, h->key);
         auto lsd_sort = [&](bool bytes_valid, const SortPlan &pl) -> int {
@@ -1212,8 +1215,8 @@ int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out) {
 static const char *const kKernelNames[IPXK_COUNT] = {
     "begin", "k_scan", "k_hist", "k_binscan", "k_skip", "k_scatter", "k_count_heads", "scan_u32",
     "k_write_heads", "k_motif", "memset", "k_reduce_a", "k_reduce", "k_finish_junctions", "k_bins",
-    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt", "ijunc_rank_sort", "k_bs_prep",
-    "k_bs_leaf"};
+    "k_emit_bins", "k_emit_junctions", "k_emit_ijunc", "copy", "k_partition", "k_adopt", "ijunc_rank_sort", "k_bs_sample",
+    "k_bs_assign", "k_bs_bounds", "k_bs_leaf"};
 
 int ipx_profile(ipx_handle *h, int enable) {
     if (!h) return IPX_EINVAL;

@@ -9,7 +9,7 @@
 // the 63-65 bits on which S's and L's keys differ: 10.8 GB per 40 M long-read records (35 % of L's step),
 // and 24 dependent launches that are all latency on S's 2 M records.  Here a record moves through HBM three
 // times whatever the key width:
-//   1. SPLITTERS.  k_bs_sample1 (one block) sorts 4096 sampled keys in LDS and keeps k1 - 1 <= 255 coarse
+//   1. SPLITTERS.  k_bs_sample1 (one block) sorts up to 4096 sampled keys in LDS and keeps k1 - 1 <= 255 coarse
 //      splitters; k_bs_sample2 deals a second, larger sample (16 keys per leaf) into the k1 coarse ranges;
 //      k_bs_sort2 (one block per coarse range) sorts its share in LDS and keeps up to 255 fine splitters.
 //      Keys are compared in a 64-bit "squeezed" form: the top 64 of the bits on which the handle's keys
@@ -26,11 +26,12 @@
 // leaf of any size whose keys are all equal needs no sorting and is accepted.
 #include "ipx_common.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
 
-constexpr uint32_t BS_NT = 1024, BS_CAP = 4096, BS_NW = BS_NT / 64, BS_IPT = BS_CAP / BS_NT;
+constexpr uint32_t BS_NT = 256, BS_CAP = 4096, BS_NW = BS_NT / 64, BS_IPT = BS_CAP / BS_NT;   // 4 waves, 16 items per thread
 constexpr uint32_t BS_SENT = 0xffffffffu;
 constexpr uint32_t BS_LISTCAP = 4096;          // second-level sample keys per coarse range (one block sorts them)
 constexpr uint32_t BS_OVERSAMPLE = 16;         // second-level sample keys per leaf
@@ -64,15 +65,24 @@ __device__ __forceinline__ uint64_t squeeze(const uint4 &it, const SqueezeSpec &
     return k;
 }
 
+// -DIPX_BS_STATS: where a leaf's cycles go (s_memtime laps on thread 0 of a few blocks, printed at the end)
+#ifdef IPX_BS_STATS
+#define BS_LAP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); st_ph[k] += now_ - st_t0; st_t0 = now_; } } while (0)
+#define BS_ST_ARGS , unsigned long long (&st_ph)[8], unsigned long long &st_t0
+#define BS_ST_PASS , st_ph, st_t0
+#else
+#define BS_LAP(k)
+#define BS_ST_ARGS
+#define BS_ST_PASS
+#endif
+
+template <uint32_t IPT>
 struct BsShared {
-    uint4 tile[BS_CAP];                  // 64 KiB
-    uint16_t cnt[BS_NW][256];            // per-wave digit counts of a pass
-    uint32_t tile_excl[256];
-    uint32_t wsum[4];
+    uint4 tile[BS_NT * IPT];             // 32 or 64 KiB
+    uint32_t cnt[BS_NW][128];            // per-wave digit counts of a pass, two 16-bit counters per word
+    uint16_t base[BS_NW][256];           // where a wave's run of a digit starts in the tile
     uint32_t vary[6];                    // OR / AND of the block's keys
-    uint32_t rng[2];
-    uint32_t n_passes;
-    SortPlan plan;
+    uint32_t rng[4];
 };
 
 // position of a thread's r-th item in the block's item order (wave, round, lane); rounds = rounds in use
@@ -81,32 +91,100 @@ __device__ __forceinline__ uint32_t bs_pos(uint32_t wave, uint32_t lane, uint32_
 }
 __device__ __forceinline__ uint32_t bs_rounds(uint32_t n) { return (n + BS_NT - 1) / BS_NT; }
 
-// Sorts the block's n <= BS_CAP items (it[r] = the item at bs_pos(wave, lane, r, rounds) where that is < n) by
-// the key bits below max_bits on which they differ; the sorted items are left in sh.tile[0, n) (visible to all
-// threads on return).  Ranking as in k_scatter (ipx_sort.hip): per-wave ballots, per-wave digit counts, one scan
-// over the 256 digits, items placed through LDS and taken back into registers for the next pass.
-__device__ __forceinline__ void bs_block_sort(BsShared &sh, uint4 (&it)[BS_IPT], uint32_t n, uint32_t max_bits) {
+// inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (six v_add_u32_dpp; the __shfl_up
+// form is six dependent ds_bpermute round trips, ~700 cycles of every pass of bs_block_sort)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// OR / AND over the wave the same way; the result is in lane 63
+__device__ __forceinline__ uint32_t wave_or_to_last(uint32_t x) {
+    uint32_t v = x;
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_and_to_last(uint32_t x) { return ~wave_or_to_last(~x); }
+
+// key words shifted right by 32 * WI + sft bits (sft < 32, wave-uniform), and back
+template <uint32_t WI>
+__device__ __forceinline__ void bs_shr(uint4 &it, uint32_t sft) {
+    const uint32_t a0 = WI == 0 ? it.x : (WI == 1 ? it.y : it.z);
+    const uint32_t a1 = WI == 0 ? it.y : (WI == 1 ? it.z : 0u);
+    const uint32_t a2 = WI == 0 ? it.z : 0u;
+    it.x = __builtin_amdgcn_alignbit(a1, a0, sft);
+    it.y = __builtin_amdgcn_alignbit(a2, a1, sft);
+    it.z = a2 >> sft;
+}
+__device__ __forceinline__ uint32_t bs_shl_word(uint32_t hi, uint32_t lo, uint32_t sft) {      // (hi:lo << sft) >> 32
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) << sft >> 32);
+}
+template <uint32_t WI>
+__device__ __forceinline__ void bs_shl(uint4 &it, uint32_t sft) {
+    const uint32_t b0 = it.x, b1 = it.y, b2 = it.z;
+    if (WI == 0) { it.x = b0 << sft; it.y = bs_shl_word(b1, b0, sft); it.z = bs_shl_word(b2, b1, sft); }
+    else if (WI == 1) { it.x = 0; it.y = b0 << sft; it.z = bs_shl_word(b1, b0, sft); }
+    else { it.x = 0; it.y = 0; it.z = b0 << sft; }
+}
+
+// what bs_block_sort leaves in the tile: the keys shifted right by `lo` bits; low = the bits below (equal in all keys)
+struct BsSorted {
+    uint32_t lo;
+    uint32_t low[3];
+};
+__device__ __forceinline__ uint4 bs_restore(uint4 it, const BsSorted &bs) {
+    const uint32_t wi = bs.lo >> 5, sft = bs.lo & 31u;
+    if (wi == 0) bs_shl<0>(it, sft); else if (wi == 1) bs_shl<1>(it, sft); else bs_shl<2>(it, sft);
+    it.x |= bs.low[0]; it.y |= bs.low[1]; it.z |= bs.low[2];
+    return it;
+}
+
+// Sorts the block's n <= 256 * IPT items (it[r] = the item at bs_pos(wave, lane, r, rounds) where that is < n) by
+// their 96-bit keys; the sorted items are left in sh.tile[0, n) (visible to all threads on return) with the keys
+// shifted right by the returned `lo` (bs_restore undoes it).  An LSD radix sort whose items live in registers
+// between passes:
+//  * the keys' OR and AND tell on which bits they differ; every key is shifted right by the lowest such bit, so
+//    that pass k looks at byte k of the shifted key (one v_bfe_u32; a digit spelled as two runs of bits at run-time
+//    positions compiled to forty scalar branches per item) and bytes on which no key differs are skipped;
+//  * slots up to the next multiple of 256 are filled with all-ones keys, which sort behind everything, so the
+//    passes know no invalid items;
+//  * ranking: ONE LDS returning atomic per item, on a 16-bit counter of its wave (two per word).  Lanes of one
+//    instruction that hit the same word get their old values in lane order on this hardware
+//    (profiles/microbench/lds_atomic_order.hip: 1.3 x 10^10 lane-ops, no exception; bsort_selftest checks it again
+//    in every process before the bucket sort is used), and a wave's LDS instructions execute in order -- so the
+//    value returned IS the item's rank among the equal digits of its wave in (round, lane) order, which is what a
+//    stable split needs.  The ballot-matching of k_scatter costs ~50 instructions per item for the same number;
+//  * two barriers per pass: after the counts every wave scans all 256 digit totals ITSELF (four digits per lane,
+//    one DPP scan) and writes only its own row of bases, which only it reads; the second barrier stands between
+//    placing the items in the tile and taking them back.
+template <uint32_t IPT>
+__device__ __forceinline__ BsSorted bs_block_sort(BsShared<IPT> &sh, uint4 (&it)[IPT], uint32_t n BS_ST_ARGS) {
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t rounds = bs_rounds(n);
+    BsSorted out{0u, {0u, 0u, 0u}};
     if (t < 6) sh.vary[t] = t < 3 ? 0u : ~0u;
     __syncthreads();
     {
         uint32_t v[6] = {0u, 0u, 0u, ~0u, ~0u, ~0u};
 #pragma unroll
-        for (uint32_t r = 0; r < BS_IPT; ++r)
+        for (uint32_t r = 0; r < IPT; ++r)
             if (r < rounds && bs_pos(wave, lane, r, rounds) < n) {
                 v[0] |= it[r].x; v[1] |= it[r].y; v[2] |= it[r].z;
                 v[3] &= it[r].x; v[4] &= it[r].y; v[5] &= it[r].z;
             }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-#pragma unroll
-            for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-                const uint32_t o = __shfl_xor(v[k], dlt);
-                v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
-            }
-        }
-        if (lane == 0) {
+        for (int k = 0; k < 3; ++k) { v[k] = wave_or_to_last(v[k]); v[3 + k] = wave_and_to_last(v[3 + k]); }
+        if (lane == 63) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (v[k]) atomicOr(&sh.vary[k], v[k]);
@@ -115,106 +193,147 @@ __device__ __forceinline__ void bs_block_sort(BsShared &sh, uint4 (&it)[BS_IPT],
         }
     }
     __syncthreads();
-    if (t == 0) {
-        const uint32_t vary[3] = {sh.vary[0] ^ sh.vary[3], sh.vary[1] ^ sh.vary[4], sh.vary[2] ^ sh.vary[5]};
-        if (n <= 1 || (vary[0] | vary[1] | vary[2]) == 0u) {
-            sh.n_passes = 0;
-        } else {
-            const SortPlan pl = ipx_plan_sort(vary, max_bits, nullptr);
-            sh.plan = pl;
-            sh.n_passes = pl.n;
-        }
-    }
-    __syncthreads();
-    const uint32_t n_passes = sh.n_passes;
-    if (n_passes == 0) {                                   // all keys equal (or none): any order is sorted
+    uint32_t vs[3], an[3];
 #pragma unroll
-        for (uint32_t r = 0; r < BS_IPT; ++r) {
+    for (int k = 0; k < 3; ++k) {
+        an[k] = __builtin_amdgcn_readfirstlane(sh.vary[3 + k]);
+        vs[k] = __builtin_amdgcn_readfirstlane(sh.vary[k]) ^ an[k];
+    }
+    BS_LAP(1);                                             // OR / AND of the keys
+    if (n <= 1 || (vs[0] | vs[1] | vs[2]) == 0u) {         // all keys equal (or none): any order is sorted
+#pragma unroll
+        for (uint32_t r = 0; r < IPT; ++r) {
             const uint32_t p = bs_pos(wave, lane, r, rounds);
             if (r < rounds && p < n) sh.tile[p] = it[r];
         }
         __syncthreads();
-        return;
+        return out;
     }
+    const uint32_t lo = vs[0] ? (uint32_t)__builtin_ctz(vs[0]) : (vs[1] ? 32u + (uint32_t)__builtin_ctz(vs[1]) : 64u + (uint32_t)__builtin_ctz(vs[2]));
+    const uint32_t wi = lo >> 5, sft = lo & 31u;
+    out.lo = lo;
+    {   // bits below lo: the same in every key
+        const uint32_t m = sft ? ((1u << sft) - 1u) : 0u;
+        out.low[0] = wi == 0 ? (an[0] & m) : an[0];
+        out.low[1] = wi == 0 ? 0u : (wi == 1 ? (an[1] & m) : an[1]);
+        out.low[2] = wi == 2 ? (an[2] & m) : 0u;
+    }
+    // shifted keys; slots past n hold all-ones keys
+    uint4 vv = make_uint4(vs[0], vs[1], vs[2], 0u);
+    if (wi == 0) {
+        bs_shr<0>(vv, sft);
+#pragma unroll
+        for (uint32_t r = 0; r < IPT; ++r) if (r < rounds) bs_shr<0>(it[r], sft);
+    } else if (wi == 1) {
+        bs_shr<1>(vv, sft);
+#pragma unroll
+        for (uint32_t r = 0; r < IPT; ++r) if (r < rounds) bs_shr<1>(it[r], sft);
+    } else {
+        bs_shr<2>(vv, sft);
+#pragma unroll
+        for (uint32_t r = 0; r < IPT; ++r) if (r < rounds) bs_shr<2>(it[r], sft);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < IPT; ++r)
+        if (r < rounds && bs_pos(wave, lane, r, rounds) >= n) it[r] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    // bytes of the shifted key on which the keys differ
+    uint32_t active = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 12; ++k) {
+        const uint32_t w = k < 4 ? vv.x : (k < 8 ? vv.y : vv.z);
+        if ((w >> (8 * (k & 3u))) & 0xffu) active |= 1u << k;
+    }
+    active = __builtin_amdgcn_readfirstlane(active);
+    const uint32_t last_k = 31u - (uint32_t)__builtin_clz(active);
+    uint2 *cnt2 = reinterpret_cast<uint2 *>(&sh.cnt[0][0]);             // [wave][64]: digits 4 * lane .. 4 * lane + 3
+    uint2 *base2 = reinterpret_cast<uint2 *>(&sh.base[0][0]);
 #pragma unroll 1
-    for (uint32_t k = 0; k < n_passes; ++k) {
-        DigitSpec d;
-        d.lo1 = __builtin_amdgcn_readfirstlane(sh.plan.digits[k].lo1);
-        d.w1 = __builtin_amdgcn_readfirstlane(sh.plan.digits[k].w1);
-        d.lo2 = __builtin_amdgcn_readfirstlane(sh.plan.digits[k].lo2);
-        d.w2 = __builtin_amdgcn_readfirstlane(sh.plan.digits[k].w2);
-        {
-            uint32_t *c32 = reinterpret_cast<uint32_t *>(&sh.cnt[wave][0]);
-            c32[lane] = 0;
-            c32[lane + 64] = 0;
-        }
+    for (uint32_t k = 0; k <= last_k; ++k) {
+        if (!((active >> k) & 1u)) continue;
+        const uint32_t sel = k >> 2, bsh = 8u * (k & 3u);
+        cnt2[wave * 64 + lane] = make_uint2(0, 0);
         __builtin_amdgcn_wave_barrier();
-        uint32_t rk[BS_IPT], dg[BS_IPT];
-#pragma unroll
-        for (uint32_t r = 0; r < BS_IPT; ++r) {
-            dg[r] = 0xffffffffu;
-            rk[r] = 0;
-            if (r < rounds) {
-                const bool ok = bs_pos(wave, lane, r, rounds) < n;
-                const uint32_t dig = ok ? ipx_digit_of(it[r], d) : 0xffffffffu;
-                dg[r] = dig;
-                uint64_t peers = ipx_ballot(ok);
-#pragma unroll
-                for (uint32_t bit = 0; bit < 8; ++bit) {
-                    const uint64_t bm = ipx_ballot((dig >> bit) & 1u);
-                    peers &= ((dig >> bit) & 1u) ? bm : ~bm;
-                }
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-                uint32_t before = 0;
-                if (ok) {
-                    before = sh.cnt[wave][dig];
-                    rk[r] = before + below;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (ok && below == 0) sh.cnt[wave][dig] = (uint16_t)(before + (uint32_t)__popcll(peers));
-                __builtin_amdgcn_wave_barrier();
-            }
+        uint32_t rd[IPT];                                  // rank among the wave's equal digits | digit << 16
+#define BS_RANK(WORD)                                                                       \
+        _Pragma("unroll") for (uint32_t r = 0; r < IPT; ++r) {                              \
+            rd[r] = 0;                                                                      \
+            if (r < rounds) {                                                               \
+                const uint32_t dig = (it[r].WORD >> bsh) & 0xffu;                           \
+                const uint32_t hs = (dig & 1u) * 16u;                                       \
+                const uint32_t old = atomicAdd(&sh.cnt[wave][dig >> 1], 1u << hs);          \
+                rd[r] = ((old >> hs) & 0xffffu) | (dig << 16);                              \
+            }                                                                               \
         }
+        if (sel == 0) { BS_RANK(x) } else if (sel == 1) { BS_RANK(y) } else { BS_RANK(z) }
+#undef BS_RANK
         __syncthreads();
-        uint32_t tot = 0, incl = 0;
-        if (t < 256) {
-            uint32_t run = 0;
+        BS_LAP(2);                                         // digits, ranks, barrier
+        {
+            uint2 tot = make_uint2(0, 0), pre = make_uint2(0, 0);           // packed pairs; no field exceeds 4096
 #pragma unroll
             for (uint32_t w = 0; w < BS_NW; ++w) {
-                const uint32_t c = sh.cnt[w][t];
-                sh.cnt[w][t] = (uint16_t)run;
-                run += c;
+                const uint2 c = cnt2[w * 64 + lane];
+                tot.x += c.x; tot.y += c.y;
+                if (w < wave) { pre.x += c.x; pre.y += c.y; }
             }
-            tot = run;
-            incl = tot;
+            const uint32_t t0 = tot.x & 0xffffu, t1 = tot.x >> 16, t2 = tot.y & 0xffffu, t3 = tot.y >> 16;
+            const uint32_t mine = t0 + t1 + t2 + t3;
+            const uint32_t excl = wave_incl_scan(mine) - mine;          // items of the digits below 4 * lane
+            const uint32_t b0 = excl + (pre.x & 0xffffu), b1 = excl + t0 + (pre.x >> 16),
+                           b2 = excl + t0 + t1 + (pre.y & 0xffffu), b3 = excl + t0 + t1 + t2 + (pre.y >> 16);
+            base2[wave * 64 + lane] = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+        }
+        __builtin_amdgcn_wave_barrier();
+        BS_LAP(3);                                         // digit totals -> bases
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t v = __shfl_up(incl, o);
-                if ((int)lane >= o) incl += v;
-            }
-            if (lane == 63) sh.wsum[wave] = incl;
-        }
+        for (uint32_t r = 0; r < IPT; ++r)
+            if (r < rounds) sh.tile[(uint32_t)sh.base[wave][rd[r] >> 16] + (rd[r] & 0xffffu)] = it[r];
         __syncthreads();
-        if (t < 256) {
-            uint32_t woff = 0;
-            for (uint32_t w = 0; w < wave; ++w) woff += sh.wsum[w];
-            sh.tile_excl[t] = woff + incl - tot;
-        }
-        __syncthreads();
+        BS_LAP(4);                                         // placement, barrier
+        if (k < last_k) {
 #pragma unroll
-        for (uint32_t r = 0; r < BS_IPT; ++r) {
-            const uint32_t dig = dg[r];
-            if (dig != 0xffffffffu) sh.tile[sh.tile_excl[dig] + sh.cnt[wave][dig] + rk[r]] = it[r];
+            for (uint32_t r = 0; r < IPT; ++r)
+                if (r < rounds) it[r] = sh.tile[bs_pos(wave, lane, r, rounds)];
         }
-        __syncthreads();
-        if (k + 1 < n_passes) {
-#pragma unroll
-            for (uint32_t r = 0; r < BS_IPT; ++r) {
-                const uint32_t p = bs_pos(wave, lane, r, rounds);
-                if (r < rounds && p < n) it[r] = sh.tile[p];
-            }
-        }
+        BS_LAP(5);                                         // items back into registers
     }
+    return out;
+}
+
+// Start-up check of the property bs_block_sort's ranking rests on (see there): random digits, few and many equal
+// ones per wave, the atomic's return value against the ballot-matched rank.  *bad counts the differences.
+__global__ __launch_bounds__(256) void k_bs_selftest(uint32_t iters, unsigned long long *bad) {
+    __shared__ uint32_t cnt[4][256];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    unsigned long long mism = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) cnt[wave][q * 64 + lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t h = (blockIdx.x * 256u + t) * 2654435761u + it * 40503u;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        const uint32_t dig = (it & 1u) ? (h % (1u + (it >> 1) % 9u)) : (h & 255u);
+        const uint32_t r_atomic = atomicAdd(&cnt[wave][dig], 1u);
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) {
+            const unsigned long long bm = ipx_ballot((dig >> b) & 1u);
+            peers &= ((dig >> b) & 1u) ? bm : ~bm;
+        }
+        const uint32_t r_ballot = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        if (r_atomic != r_ballot) ++mism;
+        // ... and the DPP prefix sum against the shuffle form
+        uint32_t ref = h & 1023u;
+        const uint32_t got = wave_incl_scan(ref);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = __shfl_up(ref, o);
+            if ((int)lane >= o) ref += x;
+        }
+        if (got != ref) ++mism;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (mism) atomicAdd(bad, mism);
 }
 
 __device__ __forceinline__ uint4 key64_item(uint64_t k) { return make_uint4((uint32_t)k, (uint32_t)(k >> 32), 0u, 0u); }
@@ -233,13 +352,13 @@ __device__ __forceinline__ uint32_t bs_upper(const uint64_t *sp, uint32_t n_sp, 
 
 // ---- 1a: first-level sample -> k1 - 1 coarse splitters (one block).  Also resets the sort's device state.
 __global__ __launch_bounds__(BS_NT) void k_bs_sample1(const uint4 *__restrict__ items, uint64_t n, SqueezeSpec sq,
-                                                      uint32_t k1, uint64_t *__restrict__ coarse,
+                                                      uint32_t k1, uint32_t m1, uint64_t *__restrict__ coarse,
                                                       uint32_t *__restrict__ list_n, uint32_t *__restrict__ overflow) {
-    __shared__ BsShared sh;
+    __shared__ BsShared<BS_IPT> sh;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    if (t < 256) list_n[t] = 0;
+    list_n[t] = 0;                            // BS_NT == 256
     if (t == 0) *overflow = 0;
-    const uint32_t m = (uint32_t)(n < BS_CAP ? n : BS_CAP);
+    const uint32_t m = (uint32_t)(n < m1 ? n : m1);
     const uint32_t rounds = bs_rounds(m);
     uint4 it[BS_IPT];
 #pragma unroll
@@ -248,9 +367,12 @@ __global__ __launch_bounds__(BS_NT) void k_bs_sample1(const uint4 *__restrict__ 
         it[r] = make_uint4(0, 0, 0, 0);
         if (r < rounds && p < m) it[r] = key64_item(squeeze(items[((uint64_t)p * n) / m], sq));
     }
-    bs_block_sort(sh, it, m, 64);
+#ifdef IPX_BS_STATS
+    unsigned long long st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0;
+#endif
+    const BsSorted bs = bs_block_sort(sh, it, m BS_ST_PASS);
     // splitter j (1 <= j < k1) = the sample at rank j * m / k1
-    if (t + 1 < k1) coarse[t] = item_key64(sh.tile[(uint32_t)(((uint64_t)(t + 1) * m) / k1)]);
+    if (t + 1 < k1) coarse[t] = item_key64(bs_restore(sh.tile[(uint32_t)(((uint64_t)(t + 1) * m) / k1)], bs));
 }
 
 // ---- 1b: second-level sample, dealt into the coarse ranges
@@ -284,7 +406,7 @@ __global__ __launch_bounds__(256) void k_bs_sample2(const uint4 *__restrict__ it
 // ---- 1c: per coarse range, its sample sorted -> up to 255 fine splitters (table padded with ~0)
 __global__ __launch_bounds__(BS_NT) void k_bs_sort2(const uint32_t *__restrict__ list_n, const uint64_t *__restrict__ lists,
                                                     uint64_t *__restrict__ fine, uint32_t *__restrict__ fine_n) {
-    __shared__ BsShared sh;
+    __shared__ BsShared<BS_IPT> sh;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, c = blockIdx.x;
     const uint32_t have = list_n[c];
     const uint32_t m = have < BS_LISTCAP ? have : BS_LISTCAP;
@@ -296,13 +418,16 @@ __global__ __launch_bounds__(BS_NT) void k_bs_sort2(const uint32_t *__restrict__
         it[r] = make_uint4(0, 0, 0, 0);
         if (r < rounds && p < m) it[r] = key64_item(lists[(uint64_t)c * BS_LISTCAP + p]);
     }
-    bs_block_sort(sh, it, m, 64);
+#ifdef IPX_BS_STATS
+    unsigned long long st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0;
+#endif
+    const BsSorted bs = bs_block_sort(sh, it, m BS_ST_PASS);
     // leaves of this range: one per BS_OVERSAMPLE sample keys (at least one, at most 256)
     uint32_t f = (m + BS_OVERSAMPLE / 2) / BS_OVERSAMPLE;
     f = f < 1 ? 1 : (f > 256 ? 256 : f);
-    if (t < 256) {
-        uint64_t v = ~0ull;
-        if (t + 1 < f) v = item_key64(sh.tile[(uint32_t)(((uint64_t)(t + 1) * m) / f)]);
+    {
+        uint64_t v = ~0ull;                                 // BS_NT == 256: one table slot per thread
+        if (t + 1 < f) v = item_key64(bs_restore(sh.tile[(uint32_t)(((uint64_t)(t + 1) * m) / f)], bs));
         fine[(uint64_t)c * 256 + t] = v;
     }
     if (t == 0) fine_n[c] = f - 1;
@@ -384,38 +509,49 @@ __global__ __launch_bounds__(256) void k_bs_bounds(const uint4 *__restrict__ ite
 }
 
 // ---- 3b: every leaf sorted in LDS, written back without its id.  direct_n != 0: the whole array is one leaf.
+// Two launches share the leaves: IPT = 8 takes those of up to 2048 records (32 KiB of tile: four blocks per CU;
+// 19 of 20 leaves), IPT = 16 the larger ones (n > n_min) and what does not fit LDS at all.
+template <uint32_t IPT>
 __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, const uint32_t *__restrict__ start,
                                                    const uint32_t *__restrict__ n_leaves_p, uint32_t direct_n,
-                                                   uint32_t max_bits, uint32_t *__restrict__ overflow) {
-    __shared__ BsShared sh;
+                                                   uint32_t n_min, uint32_t max_bits, uint32_t *__restrict__ overflow) {
+    constexpr uint32_t CAP = BS_NT * IPT;
+    __shared__ BsShared<IPT> sh;
+#ifdef IPX_BS_STATS
+    unsigned long long st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_readcyclecounter();
+    uint32_t st_leaves = 0;
+#endif
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t n_leaves = direct_n ? 1u : *n_leaves_p;
+    // thread 0 fetches a leaf's bounds one leaf ahead: two dependent loads that would otherwise open every leaf
+    uint32_t nx_s = 0, nx_e = direct_n;
+    if (t == 0 && !direct_n && blockIdx.x < n_leaves) { nx_s = start[blockIdx.x]; nx_e = start[blockIdx.x + 1]; }
 #pragma unroll 1
     for (uint32_t b = blockIdx.x; b < n_leaves; b += gridDim.x) {
         if (t == 0) {
-            uint32_t s = 0, e = direct_n;
+            uint32_t s = nx_s, e = nx_e;
             if (!direct_n) {
-                s = start[b];
-                e = s;
-                if (s != BS_SENT) {
-                    uint32_t k = b + 1;
+                if (s != BS_SENT && e == BS_SENT) {
+                    uint32_t k = b + 2;
                     while ((e = start[k]) == BS_SENT) ++k;          // start[n_leaves] is always set
                 }
+                const uint32_t nb = b + gridDim.x;
+                if (nb < n_leaves) { nx_s = start[nb]; nx_e = start[nb + 1]; }
             }
             sh.rng[0] = s;
             sh.rng[1] = e;
         }
         __syncthreads();
         const uint32_t s = sh.rng[0], n = sh.rng[1] - s;
-        if (s == BS_SENT || n == 0) {
+        if (s == BS_SENT || n <= n_min || (n > CAP && CAP < BS_CAP)) {       // nothing here, or the other launch's leaf
             __syncthreads();
             continue;
         }
-        if (n <= BS_CAP) {
+        if (n <= CAP) {
             const uint32_t rounds = bs_rounds(n);
-            uint4 it[BS_IPT];
+            uint4 it[IPT];
 #pragma unroll
-            for (uint32_t r = 0; r < BS_IPT; ++r) {
+            for (uint32_t r = 0; r < IPT; ++r) {
                 const uint32_t p = bs_pos(wave, lane, r, rounds);
                 it[r] = make_uint4(0, 0, 0, 0);
                 if (r < rounds && p < n) {
@@ -423,8 +559,12 @@ __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, co
                     it[r].z &= 0xffffu;
                 }
             }
-            bs_block_sort(sh, it, n, max_bits);
-            for (uint32_t slot = t; slot < n; slot += BS_NT) items[(uint64_t)s + slot] = sh.tile[slot];
+            BS_LAP(0);                                     // bounds, loads issued (their wait falls into the next lap)
+            const BsSorted bs = bs_block_sort(sh, it, n BS_ST_PASS);
+            for (uint32_t slot = t; slot < n; slot += BS_NT) items[(uint64_t)s + slot] = bs_restore(sh.tile[slot], bs);
+#ifdef IPX_BS_STATS
+            ++st_leaves;
+#endif
         } else {
             // too large for LDS: acceptable only if its keys are all equal.  The ids come off either way.
             uint32_t v[6] = {0u, 0u, 0u, ~0u, ~0u, ~0u};
@@ -444,7 +584,14 @@ __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, co
             if (ipx_ballot(differ || other) && lane == 0) atomicOr(overflow, 1u);
         }
         __syncthreads();
+        BS_LAP(6);                                         // store + end-of-leaf barrier
     }
+#ifdef IPX_BS_STATS
+    if (t == 0 && st_leaves && (blockIdx.x % 97) == 0)
+        printf("leaf<%u> block %u: %u leaves; cycles per leaf: load %llu, or/and %llu, rank %llu, scan %llu, place %llu, back %llu, store %llu\n",
+               IPT, blockIdx.x, st_leaves, st_ph[0] / st_leaves, st_ph[1] / st_leaves, st_ph[2] / st_leaves,
+               st_ph[3] / st_leaves, st_ph[4] / st_leaves, st_ph[5] / st_leaves, st_ph[6] / st_leaves);
+#endif
 }
 
 SqueezeSpec make_squeeze(const uint32_t vary[3], uint32_t total_bits) {
@@ -473,8 +620,27 @@ SqueezeSpec make_squeeze(const uint32_t vary[3], uint32_t total_bits) {
 
 }  // namespace
 
+// Once per process: does an LDS returning atomic rank the lanes that hit one address in lane order (bs_block_sort)?
+// 64 blocks x 256 threads x 400 rounds against the ballot-matched rank, ~0.1 ms.  A device that fails it, or any HIP
+// error on the way, leaves the bucket sort switched off: ipx_finalize then sorts by radix passes as before.
+static bool bsort_selftest() {
+    static const bool ok = [] {
+        unsigned long long *bad = nullptr, h = 1;
+        if (hipMalloc(&bad, sizeof h) != hipSuccess) return false;
+        bool good = hipMemset(bad, 0, sizeof h) == hipSuccess;
+        if (good) {
+            hipLaunchKernelGGL(k_bs_selftest, dim3(64), dim3(256), 0, 0, 400u, bad);
+            good = hipGetLastError() == hipSuccess && hipMemcpy(&h, bad, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h == 0;
+        }
+        (void)hipFree(bad);
+        if (!good) fprintf(stderr, "ipx: LDS atomics do not rank equal lanes in lane order on this device: bucket sort off\n");
+        return good;
+    }();
+    return ok;
+}
+
 bool ipx_bsort_applicable(uint64_t n, const KeyLayout &kl) {
-    return n >= 1 && kl.total_bits <= BS_ID_LO && n <= (uint64_t)BS_MAX_LEAVES * BS_LEAF_AVG && n < (1ull << 32);
+    return n >= 1 && kl.total_bits <= BS_ID_LO && n <= (uint64_t)BS_MAX_LEAVES * BS_LEAF_AVG && n < (1ull << 32) && bsort_selftest();
 }
 
 size_t ipx_bsort_workspace_bytes(void) {
@@ -502,7 +668,10 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
     if (n <= BS_CAP) {                            // one leaf: one launch
         hipError_t e = hipMemsetAsync(overflow, 0, sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_bs_leaf, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, kl.total_bits, overflow);
+        if (n <= BS_CAP / 2)
+            hipLaunchKernelGGL(k_bs_leaf<BS_IPT / 2>, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, 0u, kl.total_bits, overflow);
+        else
+            hipLaunchKernelGGL(k_bs_leaf<BS_IPT>, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, 0u, kl.total_bits, overflow);
         ipx_prof_mark(s, IPXK_BS_LEAF);
         return hipGetLastError();
     }
@@ -513,14 +682,16 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
     // and few enough leaves per range that an uneven range stays below 256
     uint32_t k1 = (uint32_t)std::max<uint64_t>(ipx_div_up(m2, 1800), ipx_div_up(k_target, 170));
     k1 = std::min<uint32_t>(std::max<uint32_t>(k1, 1u), 256u);
-    hipLaunchKernelGGL(k_bs_sample1, dim3(1), dim3(BS_NT), 0, s, buf_a, n, sq, k1, coarse, list_n, overflow);
+    const uint32_t m1 = std::min<uint32_t>(std::max<uint32_t>(16u * k1, 256u), BS_CAP);     // 16 first-level sample keys per coarse range
+    hipLaunchKernelGGL(k_bs_sample1, dim3(1), dim3(BS_NT), 0, s, buf_a, n, sq, k1, m1, coarse, list_n, overflow);
     hipLaunchKernelGGL(k_bs_sample2, dim3((uint32_t)ipx_div_up(m2, 256)), dim3(256), 0, s, buf_a, n, m2, sq, k1, coarse, list_n, lists);
     hipLaunchKernelGGL(k_bs_sort2, dim3(k1), dim3(BS_NT), 0, s, list_n, lists, fine, fine_n);
+    ipx_prof_mark(s, IPXK_BS_SAMPLE);
     const uint32_t assign_blocks = (uint32_t)std::min<uint64_t>(ipx_div_up(n, 256 * 4), (uint64_t)n_cus * 16);
     hipLaunchKernelGGL(k_bs_assign, dim3(assign_blocks), dim3(256), 0, s, buf_a, dig_a, n, sq, k1, coarse, fine, fine_n, n_leaves);
     hipError_t e = hipMemsetAsync(start, 0xff, (size_t)65540 * 4, s);
     if (e != hipSuccess) return e;
-    ipx_prof_mark(s, IPXK_BS_PREP);
+    ipx_prof_mark(s, IPXK_BS_ASSIGN);
     SortPlan plan{};
     plan.n = 2;
     plan.digits[0] = DigitSpec{BS_ID_LO, 8, 0, 0};
@@ -529,9 +700,11 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
     if ((e = ipx_launch_sort(s, buf_a, buf_b, dig_a, dig_b, true, n, plan, sort_ws, sort_ws_bytes, -1, &id_low)) != hipSuccess) return e;
     // two passes: the records are back in buf_a, the low id bytes the second pass wrote in dig_a
     hipLaunchKernelGGL(k_bs_bounds, dim3((uint32_t)ipx_div_up(ipx_div_up(n, 16), 256)), dim3(256), 0, s, buf_a, dig_a, n, n_leaves, start);
-    ipx_prof_mark(s, IPXK_BS_PREP);
-    const uint32_t leaf_blocks = (uint32_t)std::min<uint64_t>(k_target + k1, (uint64_t)n_cus * 8);
-    hipLaunchKernelGGL(k_bs_leaf, dim3(leaf_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, kl.total_bits, overflow);
+    ipx_prof_mark(s, IPXK_BS_BOUNDS);
+    const uint32_t leaf_blocks = (uint32_t)std::min<uint64_t>(k_target + k1, (uint64_t)n_cus * 16);
+    hipLaunchKernelGGL(k_bs_leaf<BS_IPT / 2>, dim3(leaf_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, 0u, kl.total_bits, overflow);
+    const uint32_t big_blocks = (uint32_t)std::min<uint64_t>(k_target / 8 + 1, (uint64_t)n_cus * 2);
+    hipLaunchKernelGGL(k_bs_leaf<BS_IPT>, dim3(big_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, BS_CAP / 2, kl.total_bits, overflow);
     ipx_prof_mark(s, IPXK_BS_LEAF);
     return hipGetLastError();
 }

@@ -289,7 +289,7 @@ enum IpxKernelId {
     IPXK_SCAN, IPXK_SORT_HIST, IPXK_SORT_SCAN, IPXK_SORT_SKIP, IPXK_SORT_SCATTER,
     IPXK_COUNT_HEADS, IPXK_SCAN_U32, IPXK_WRITE_HEADS, IPXK_MOTIF, IPXK_MEMSET, IPXK_PHASE_A,
     IPXK_PHASE_B, IPXK_FINISH_J, IPXK_BINS, IPXK_EMIT_BINS, IPXK_EMIT_J, IPXK_EMIT_IJUNC,
-    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_RANK_SORT, IPXK_BS_PREP, IPXK_BS_LEAF, IPXK_COUNT
+    IPXK_COPY, IPXK_PARTITION, IPXK_ADOPT, IPXK_RANK_SORT, IPXK_BS_SAMPLE, IPXK_BS_ASSIGN, IPXK_BS_BOUNDS, IPXK_BS_LEAF, IPXK_COUNT
 };
 void ipx_prof_mark(hipStream_t s, int id);
 // before a launch of class id: opens the interval when that class alone is being timed (ipx_profile_only)

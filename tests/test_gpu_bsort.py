@@ -1,5 +1,5 @@
 """GPU parity for the two sorts of ipx_finalize: the bucket sort (csrc/ipx_bsort.hip: sampled splitters, two radix
-passes on a 16-bit leaf id, every leaf sorted in LDS) takes tables from 32 768 records on, the LSD radix sort
+passes on a 16-bit leaf id, every leaf sorted in LDS) takes tables from 4 M records on, the LSD radix sort
 (csrc/ipx_sort.hip) the rest and the bucket sort's overflow cases.  IPX_BSORT_MIN / IPX_SORT force either on any size.
 Every case compares the whole device table with the oracle's (std::map order, junctions.hh:77-100)."""
 import numpy as np
@@ -7,7 +7,7 @@ import pytest
 import torch            # noqa: F401  (before libipx.so, as in test_gpu_parity.py)
 
 from tests import helpers
-from tests.test_gpu_parity import _run_both
+from tests.test_gpu_parity import _fetcher, _run_both
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,7 @@ def test_bucket_sort_with_genome_filter_and_global_scope(monkeypatch, tmp_path):
     for scope in (0, 1):
         dev, ora, err = _run_both(batch, names, {"junction_filter": 1}, genome=genome, fasta=fasta, scope=scope, n_push=2)
         assert err is None
-        helpers.compare_tables(dev, ora)
+        helpers.compare_tables(dev, ora, _fetcher(genome))
 
 
 def test_lsd_sort_still_serves_large_tables(monkeypatch):
@@ -61,9 +61,12 @@ def test_lsd_sort_still_serves_large_tables(monkeypatch):
     helpers.compare_tables(dev, ora)
 
 
-def test_default_sort_choice_on_a_large_table():
+def test_bucket_sort_on_a_million_records(monkeypatch):
+    """a few hundred leaves per coarse range, both leaf size classes"""
     from intronprospector_amd import synth
-    batch, names, _ = synth.short_reads(1_200_000, seed=69, n_targets=4, target_len=30_000_000, n_sites=60_000)
+    monkeypatch.setenv("IPX_BSORT_MIN", "1")
+    monkeypatch.setenv("IPX_COMBINE", "0")
+    batch, names, _ = synth.short_reads(1_200_000, seed=69, n_targets=4, target_len=30_000_000, n_sites=400_000)
     dev, ora, err = _run_both(batch, names, {}, n_push=2)
     assert err is None
     assert dev["n_records"] > 1_000_000

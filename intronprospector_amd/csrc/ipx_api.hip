@@ -425,6 +425,7 @@ GenomeDev genome_dev(const ipx_handle *h) {
 extern "C" {
 
 static int push_complete(ipx_handle *h);      // books a batch that ipx_push_batch_async left in flight
+static int report_data_error(ipx_handle *h, unsigned long long err_word);
 
 uint32_t ipx_abi_version(void) { return IPX_ABI_VERSION; }
 
@@ -768,8 +769,14 @@ static int push_complete(ipx_handle *h) {
         if (pp.is_bam && tail4[1] != 0xffffffffu) {
             // what the host parser throws "Error reader BAM record" for; the scan's records of this batch are dropped
             const uint32_t bad = tail4[1];
+            const unsigned long long earlier = c->err_word;       // earliest data error so far, this batch's scan included
             hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), pp.before);
             HIPCHK(hipGetLastError());
+            // The reference's loop throws at the FIRST defect in input order (junctions_extractor.cc:620-664): a data
+            // error of an alignment before the record that does not parse is the one to report
+            if (earlier != IPX_ERRW_NONE && ((earlier >> 8) & 3u) != IPX_ERRK_GENOME &&
+                IPX_ORD_READ(earlier) < pp.db.base_read_index + (uint64_t)bad - 1)
+                return report_data_error(h, earlier);
             return fail(h, IPX_EINVAL, "ipx_push_bam: malformed BAM record%s (alignment %ld of the batch)", "", (long)bad - 1);
         }
         if (getenv("IPX_DEBUG_PLAN"))

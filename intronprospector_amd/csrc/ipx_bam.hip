@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ 
                     const uint32_t cnt = ld32(bytes, b + p + 1);
                     const uint64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                     sz = 5 + es * (uint64_t)cnt;
-                    if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = b + p + 5; cg_n = cnt; have_cg = true; }
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && !have_cg) { cg = b + p + 5; cg_n = cnt; have_cg = true; }   // the first CG tag, as bam_aux_get
                     break;
                 }
                 default: ok = false; break;

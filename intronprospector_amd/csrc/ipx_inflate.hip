@@ -208,6 +208,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 if (!build(lens, hlit, LLB, ll, sll, cll)) { err = 2; break; }
             }
             // symbols
+            bool eob = false;
             for (uint32_t sguard = 0; sguard < 70000; ++sguard) {        // every symbol but the last writes a byte
                 b.fill();
                 const uint32_t sym = decode(b, ll, LLB, sll, cll);
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                     o[n_out++] = (uint8_t)sym;
                     continue;
                 }
-                if (sym == 256) break;
+                if (sym == 256) { eob = true; break; }
                 if (sym > 285) { err = 3; break; }
                 const uint32_t len = C_LEN_BASE[sym - 257] + b.take(C_LEN_EXTRA[sym - 257]);
                 b.fill();
@@ -238,10 +239,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 }
                 for (; k < len; ++k, ++n_out) o[n_out] = o[n_out - dist];
             }
+            if (!err && !eob) err = 8;                                   // the guard ran out before an end-of-block symbol
         } else {
             err = 1;
         }
-        if (final_block) break;
+        if (final_block || err) break;
     }
     if (!err && b.past * 8 > b.cnt) err = 6;                            // bits were taken from beyond the block's end
     if (!err && n_out != cap) err = 7;
@@ -255,7 +257,10 @@ extern "C" int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_
                                 uint64_t out_bytes, uint32_t *status, float *kernel_ms) {
     if (!comp || !in_off || !isize || !out_off || !out || !status || n_blocks == 0) return IPX_EINVAL;
     for (uint64_t b = 0; b < n_blocks; ++b)
-        if (in_off[b] > in_off[b + 1] || in_off[b + 1] > n_bytes || isize[b] > 65536 || out_off[b] + isize[b] > out_bytes) return IPX_EINVAL;
+        // (no sum that could wrap; output ranges ascending and apart, so that no two lanes write the same bytes)
+        if (in_off[b] > in_off[b + 1] || in_off[b + 1] > n_bytes || isize[b] > 65536 || out_off[b] > out_bytes ||
+            isize[b] > out_bytes - out_off[b] || (b > 0 && out_off[b] < out_off[b - 1] + isize[b - 1]))
+            return IPX_EINVAL;
     if (hipSetDevice(device) != hipSuccess) return IPX_ENODEVICE;
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     uint64_t *d_in_off = nullptr, *d_out_off = nullptr;

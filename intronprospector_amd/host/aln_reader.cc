@@ -232,15 +232,12 @@ void parse_bam_record(const uint8_t *b, uint32_t block, const std::string &path_
         size_t p = off + 3, sz = 0;
         long long ival = 0;
         bool is_int = false;
+        // the value's size first, checked against the record, and only then the value (a record whose last tag is
+        // cut short must not make this read past the block)
         switch (type) {
-            case 'A': sz = 1; break;
-            case 'c': sz = 1; ival = (int8_t)b[p]; is_int = true; break;
-            case 'C': sz = 1; ival = b[p]; is_int = true; break;
-            case 's': sz = 2; ival = (int16_t)(b[p] | (b[p + 1] << 8)); is_int = true; break;
-            case 'S': sz = 2; ival = (uint16_t)(b[p] | (b[p + 1] << 8)); is_int = true; break;
-            case 'i': sz = 4; ival = (int32_t)le32(b + p); is_int = true; break;
-            case 'I': sz = 4; ival = le32(b + p); is_int = true; break;
-            case 'f': sz = 4; break;
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
             case 'd': sz = 8; break;
             case 'Z': case 'H': {
                 size_t q = p;
@@ -254,12 +251,24 @@ void parse_bam_record(const uint8_t *b, uint32_t block, const std::string &path_
                 const uint32_t cnt = le32(b + p + 1);
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                 sz = 5 + es * (size_t)cnt;
-                if (t[0] == 'C' && t[1] == 'G' && sub == 'I') { cg = b + p + 5; cg_n = cnt; }
                 break;
             }
             default: throw std::runtime_error("Error reader BAM record: " + path_);
         }
         if (p + sz > block) throw std::runtime_error("Error reader BAM record: " + path_);
+        switch (type) {
+            case 'c': ival = (int8_t)b[p]; is_int = true; break;
+            case 'C': ival = b[p]; is_int = true; break;
+            case 's': ival = (int16_t)(b[p] | (b[p + 1] << 8)); is_int = true; break;
+            case 'S': ival = (uint16_t)(b[p] | (b[p + 1] << 8)); is_int = true; break;
+            case 'i': ival = (int32_t)le32(b + p); is_int = true; break;
+            case 'I': ival = le32(b + p); is_int = true; break;
+            case 'B':
+                // bam_aux_get returns the FIRST tag of a name: a second CG array does not replace the first
+                if (t[0] == 'C' && t[1] == 'G' && (char)b[p] == 'I' && !cg) { cg = b + p + 5; cg_n = le32(b + p + 1); }
+                break;
+            default: break;
+        }
         if (t[0] == 'X' && t[1] == 'S' && !have_xs) {
             have_xs = true;
             char c = (type == 'A') ? (char)b[p] : 0;

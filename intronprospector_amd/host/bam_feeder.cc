@@ -172,15 +172,17 @@ void BamFeeder::wait_all() {
 void BamFeeder::worker() {
     for (;;) {
         Task t;
+        bool stopping = false;
         {
             std::unique_lock<std::mutex> lk(m_);
             have_task_.wait(lk, [&] { return stop_ || !queue_.empty(); });
             if (queue_.empty()) return;                                 // stop_ and nothing left
             t = std::move(queue_.front());
             queue_.pop_front();
+            stopping = stop_;
         }
         try {
-            run(t);
+            if (!stopping) run(t);                                      // stopping: queued spans are dropped, not parsed
         } catch (...) {
             std::lock_guard<std::mutex> lk(m_);
             if (!error_) error_ = std::current_exception();

@@ -60,11 +60,12 @@ static int dump_feed(const char *path, bool by_target, size_t cap_aln, size_t ca
     if (!rd.bgzf()) { fprintf(stderr, "not a BGZF-compressed BAM file\n"); return 1; }
     std::vector<int32_t> canon(rd.target_names().size());
     for (size_t i = 0; i < canon.size(); ++i) canon[i] = (int32_t)i;
-    BamFeeder feeder(*rd.bgzf(), path, canon);
+    // (the arrays before the feeder: its workers write into them until its destructor has joined them)
     std::vector<int32_t> tid(cap_aln), pos(cap_aln);
     std::vector<uint16_t> flag(cap_aln);
     std::vector<uint8_t> xs(cap_aln), nh(cap_aln);
     std::vector<uint32_t> off(cap_aln), nc(cap_aln), cigar(cap_words);
+    BamFeeder feeder(*rd.bgzf(), path, canon);
     size_t n = 0, nw = 0;
     auto flush = [&]() {
         feeder.wait_all();

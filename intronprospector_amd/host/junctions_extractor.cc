@@ -121,6 +121,10 @@ JunctionsExtractor::~JunctionsExtractor() {
                   << ", \"open_s\": " << t_open_ << ", \"identify_s\": " << t_identify_ << ", \"get_junctions_s\": " << t_getj_
                   << ", \"close_s\": " << t_close_ << ", \"extractor_lifetime_s\": " << now_s() - t_born_ << "}}" << std::endl;
     if (init_thread_.joinable()) init_thread_.join();
+    // The feeder's workers parse straight into the pinned batches: stop and join them BEFORE that memory goes (an
+    // exception that unwinds out of the read loop -- a damaged block, a truncated record -- leaves spans dispatched;
+    // as a member the feeder would only be destroyed after this body had freed the batches under the workers).
+    feeder_.reset();
     if (h_) ipx_destroy(h_);
     if (g_) ipx_group_destroy(g_);
     for (HostBatch &b : batch_) {
@@ -390,14 +394,18 @@ bool JunctionsExtractor::feed_target(int32_t target_index, int32_t *other_tid) {
         if (st == BamFeeder::SPAN) {
             const size_t bytes = sp.end - sp.begin;
             if (b->raw_n + bytes > b->raw_cap) {
+                size_t filled_cap = 0;
                 if (b->n) {                        // this set is full: the run opens the other one
+                    filled_cap = b->raw_cap;
                     flush_batch();
                     b = &batch_[cur_];
                     if (b->tables_lent) { b->span_begin.clear(); b->span_first.clear(); b->tables_lent = false; }
                 }
-                if (!b->raw || bytes > b->raw_cap) {
+                // the second set is sized like the first (it used to start at 1 MB and, a span being at most 64 KiB,
+                // never grew: batches alternated 96 MB / 1 MB and the small one's push waited for the large one)
+                if (!b->raw || bytes > b->raw_cap || b->raw_cap < filled_cap) {
                     const size_t want = std::min(RAW_BATCH_BYTES, std::max(b->raw_cap * 8, (size_t)1 << 20));
-                    size_raw(*b, std::max(want, bytes));
+                    size_raw(*b, std::max(std::max(want, bytes), filled_cap));
                 }
             }
             b->span_begin.push_back(b->raw_n);

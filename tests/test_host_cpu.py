@@ -353,3 +353,49 @@ def test_fast_inflate_against_zlib(host_check, tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     rep = json.loads(r.stdout)
     assert rep["streams"] == n and rep["damaged"] >= 8 * (n - 20) and 0 < rep["damaged_still_valid"] < rep["damaged"]
+
+
+def test_damaged_bam_under_address_sanitizer(tmp_path):
+    """The reader's failure paths under AddressSanitizer (CPU build of the host sources): a BAM whose LATE block is
+    damaged, read by the block-parallel feeder with two parse threads -- the exception unwinds while spans are still
+    dispatched, and the workers must be stopped before the arrays they fill go away (the extractor's destructor and
+    ipx_host_check's dump-feed keep that order); and a record whose last tag is cut short by its block_size -- the
+    parser checks a value's size against the record before it reads the value."""
+    import struct
+    host = os.path.join(ROOT, "intronprospector_amd", "host")
+    exe = str(tmp_path / "ipx_host_check_asan")
+    srcs = [os.path.join(host, f) for f in ("host_check.cc", "junctions.cc", "aln_reader.cc", "bgzf_reader.cc", "fast_inflate.cc",
+                                            "bam_feeder.cc", "pass_through.cc")]
+    subprocess.run(["g++", "-O1", "-g", "-std=c++14", "-pthread", "-fsanitize=address", "-fno-omit-frame-pointer", "-o", exe] + srcs + ["-lz"],
+                   check=True)
+    env = dict(os.environ, IPX_PARSE_THREADS="2", ASAN_OPTIONS="detect_leaks=0")
+    good = str(tmp_path / "many.bam")
+    subprocess.run([exe, "make-bam", "120000", good], check=True, env=env)
+    raw = bytearray(open(good, "rb").read())
+    r = subprocess.run([exe, "dump-feed", good, "all", "5000", "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0 and b"AddressSanitizer" not in r.stderr
+    for where in (0.6, 0.8, 0.97):
+        bad = str(tmp_path / "late.bam")
+        flipped = bytearray(raw)
+        k = int(len(raw) * where)
+        for j in range(k, k + 40):
+            flipped[j] ^= 0x5a
+        open(bad, "wb").write(flipped)
+        for args in (["all", "5000", "20000"], ["by-target", "100000", "800000"]):
+            r = subprocess.run([exe, "dump-feed", bad] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+            assert r.returncode != 0 and b"AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+            assert b"Error reader BAM record" in r.stderr or b"BGZF" in r.stderr or b"inflate" in r.stderr, r.stderr[-500:]
+    # one record, its NH:i tag's value cut off: block_size says the record ends two bytes into the value
+    name = b"r1\0"
+    cigar = struct.pack("<III", 40 << 4, (500 << 4) | 3, 60 << 4)
+    core = struct.pack("<iiBBHHHIiii", 0, 1000, len(name), 60, 4680, 3, 0, 100, -1, -1, 0)
+    body = core + name + cigar + bytes(50) + bytes([30]) * 100 + b"NHi\x01\x00"          # 4-byte value, two bytes present
+    rec = struct.pack("<I", len(body)) + body
+    hdr_text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:1000000\n"
+    header = b"BAM\1" + struct.pack("<I", len(hdr_text)) + hdr_text + struct.pack("<I", 1) + struct.pack("<I", 5) + b"chr1\0" + struct.pack("<I", 1000000)
+    cut = str(tmp_path / "cut.bam")
+    with open(cut, "wb") as f:
+        f.write(bamio._bgzf_block(header) + bamio._bgzf_block(rec) + bamio._bgzf_block(b""))
+    for cmd in (["dump-aln", cut], ["dump-feed", cut, "all"]):
+        r = subprocess.run([exe] + cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+        assert r.returncode != 0 and b"Error reader BAM record" in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr[-2000:]

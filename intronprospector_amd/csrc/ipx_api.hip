@@ -129,6 +129,8 @@ struct ipx_handle {
     // records
     DevBuf items_a, items_b, pays, cnts, dig_a, dig_b;
     bool opt_combine = true;       // IPX_OPT_COMBINE: the short-read scan may merge equal-key records of a tile
+    bool comb_probe = false;       // the last batch found too little to merge: only every sixteenth tile still tries
+    uint32_t bsort_skip = 0;       // finalizes that go straight to the radix passes after the bucket sort overflowed
     uint64_t n_raw = 0;            // junction records that passed junction_qc (>= n_records once records were combined)
     uint32_t key_or[3] = {0, 0, 0}, key_and[3] = {~0u, ~0u, ~0u};   // host copy of Counters::key_or/and
     uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
@@ -671,6 +673,10 @@ static int push_launch(ipx_handle *h) {
     const bool combine_env = !(combine_e && combine_e[0] == '0');
     const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
     sp.combine = (h->opt_combine && combine_env) ? (filter_active ? 2u : 1u) : 0u;
+    {
+        const char *adapt_e = getenv("IPX_COMBINE_ADAPT");        // "0": never probe (tests compare both)
+        sp.combine_mask = (sp.combine && h->comb_probe && !(adapt_e && adapt_e[0] == '0')) ? 15u : 0u;
+    }
     sp.skip_missing = h->params.skip_missing_targets;
     sp.rank_is_tid = h->params.scope == IPX_SCOPE_TARGET ? 1u : 0u;
     if (filter_active) sp.genome = genome_dev(h);
@@ -780,10 +786,19 @@ static int push_complete(ipx_handle *h) {
             return fail(h, IPX_EINVAL, "ipx_push_bam: malformed BAM record%s (alignment %ld of the batch)", "", (long)bad - 1);
         }
         if (getenv("IPX_DEBUG_PLAN"))
-            fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away, %u alignments left to the second stage\n",
-                    (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged, n_defer);
+            fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away%s, %u alignments left to the second stage\n",
+                    (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged,
+                    pp.sp.combine_mask ? " (probing: one tile in sixteen combines)" : "", n_defer);
         // (the second stage ran behind the first on the device, see ipx_launch_scan; the count sizes the next one's grid)
         h->rest_hint = n_defer;
+        // the combiner adapts: little merged -> the next batches only probe; the probe tiles merge again -> back
+        if (!pp.use_ops && pp.sp.combine && c->n_records > h->n_records) {
+            const double raw = (double)(c->n_records - h->n_records) + (double)merged;
+            if (raw >= 65536.0) {
+                if (pp.sp.combine_mask == 0) { if ((double)merged < 0.10 * raw) h->comb_probe = true; }
+                else if (16.0 * (double)merged >= 0.25 * raw) h->comb_probe = false;
+            }
+        }
         if (!layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->err_word_host = c->err_word;
@@ -945,17 +960,19 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         uint32_t *tot = h->d_small.as<uint32_t>();      // [0] junctions, [1] bins, [2] the bucket sort's overflow flag
         // Which sort: the bucket sort (ipx_bsort.hip: every record moves through HBM three times whatever the key
         // width) from IPX_BSORT_MIN records on, the LSD radix sort below that, for keys without 16 spare bits, and
-        // when a leaf of the bucket sort did not fit LDS.  Default 4 M records: measured on one MI355X the two are
-        // level at 2 M records (S: 0.720 / 0.718 ms per step, fourteen launches against twenty-four) and the bucket
-        // sort wins where the radix passes are bandwidth-bound (L, 40 M records: 7.22 / 7.37 ms).  IPX_SORT=lsd:
-        // always LSD; tests force either.
+        // when a leaf of the bucket sort did not fit LDS.  Default 16 M records: measured on one MI355X the two are
+        // level at 2 M records (S: 0.720 / 0.718 ms per step, fourteen launches against twenty-four), the radix
+        // passes are ahead at 10 M records in random order (S shuffled: sort 0.66 / 0.71 ms: the leaf search of
+        // k_bs_assign is latency-bound on random keys) and the bucket sort wins where the passes are bandwidth-bound
+        // (L, 40 M records: 7.22 / 7.37 ms per step).  IPX_SORT=lsd: always LSD; tests force either.
         const uint64_t bsort_min = [] {                   // read per call: tests switch between runs
             const char *m = getenv("IPX_SORT");
             if (m && m[0] == 'l') return ~0ull;
             const char *e = getenv("IPX_BSORT_MIN");
-            return e ? (uint64_t)atoll(e) : (4ull << 20);
+            return e ? (uint64_t)atoll(e) : (16ull << 20);
         }();
         bool by_buckets = resort && R >= bsort_min && ipx_bsort_applicable(R, h->key);
+        if (by_buckets && h->bsort_skip) { --h->bsort_skip; by_buckets = false; }     // it overflowed recently on this handle
         auto lsd_sort = [&](bool bytes_valid, const SortPlan &pl) -> int {
             HIPCHK(ipx_launch_sort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
                                    h->dig_b.as<uint8_t>(), bytes_valid, R, pl, h->sort_ws.p, h->sort_ws.cap));
@@ -997,6 +1014,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             // a leaf did not fit LDS: the records are all there, keys intact, in some order -> the LSD sort
             if (getenv("IPX_DEBUG_PLAN")) fprintf(stderr, "ipx: bucket sort overflowed a leaf, sorting %llu records by radix passes\n", (unsigned long long)R);
             by_buckets = false;
+            h->bsort_skip = 15;
             if ((rc = lsd_sort(false, ideal))) return rc;
         }
         SortedItems si{h->items_a.as<uint4>(), R};

@@ -422,15 +422,34 @@ __global__ __launch_bounds__(BS_NT) void k_bs_sort2(const uint32_t *__restrict__
     unsigned long long st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = 0;
 #endif
     const BsSorted bs = bs_block_sort(sh, it, m BS_ST_PASS);
-    // leaves of this range: one per BS_OVERSAMPLE sample keys (at least one, at most 256)
+    // leaves of this range: one per BS_OVERSAMPLE sample keys (at least one, at most 256): candidate t + 1 of f - 1 is
+    // the sample key at rank (t + 1) * m / f.  A key with so many copies that it makes up a run of the sorted sample
+    // (10 equal sample keys stand for ~0.6 of a leaf) is FENCED: it is emitted as the pair v, v + 1, so that the leaf
+    // between them holds the copies of v and nothing else (in squeezed form) -- k_bs_leaf accepts a leaf of any size
+    // whose keys are all equal; unfenced, such a key shares its leaf with whole neighbouring keys and overflows it.
+    // A candidate equal to its predecessor is dropped.  At most 255 splitters: what does not fit is dropped too.
     uint32_t f = (m + BS_OVERSAMPLE / 2) / BS_OVERSAMPLE;
     f = f < 1 ? 1 : (f > 256 ? 256 : f);
-    {
-        uint64_t v = ~0ull;                                 // BS_NT == 256: one table slot per thread
-        if (t + 1 < f) v = item_key64(bs_restore(sh.tile[(uint32_t)(((uint64_t)(t + 1) * m) / f)], bs));
-        fine[(uint64_t)c * 256 + t] = v;
+    uint64_t v = ~0ull;
+    uint32_t emit = 0;
+    if (t + 1 < f) {
+        const uint32_t r = (uint32_t)(((uint64_t)(t + 1) * m) / f);
+        v = item_key64(bs_restore(sh.tile[r], bs));
+        const bool dup = t >= 1 && v == item_key64(bs_restore(sh.tile[(uint32_t)(((uint64_t)t * m) / f)], bs));
+        const bool heavy = v != ~0ull && ((r + 10 < m && item_key64(bs_restore(sh.tile[r + 10], bs)) == v) ||
+                                          (r >= 10 && item_key64(bs_restore(sh.tile[r - 10], bs)) == v));
+        emit = dup ? 0u : (heavy ? 2u : 1u);
     }
-    if (t == 0) fine_n[c] = f - 1;
+    const uint32_t incl = wave_incl_scan(emit);
+    __syncthreads();                                        // (everybody is done with sh.vary)
+    if (lane == 63) sh.rng[wave] = incl;
+    fine[(uint64_t)c * 256 + t] = ~0ull;                    // BS_NT == 256: the table's padding
+    __syncthreads();
+    uint32_t pos = incl - emit, total = 0;
+    for (uint32_t w = 0; w < BS_NW; ++w) { if (w < wave) pos += sh.rng[w]; total += sh.rng[w]; }
+    if (emit >= 1 && pos < 255) fine[(uint64_t)c * 256 + pos] = v;
+    if (emit == 2 && pos + 1 < 255) fine[(uint64_t)c * 256 + pos + 1] = v + 1;
+    if (t == 0) fine_n[c] = total < 255 ? total : 255;
 }
 
 // ---- 2: leaf id of every record into key bits 80..95, its low byte as the first pass's digit byte
@@ -594,21 +613,41 @@ __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, co
 #endif
 }
 
+// The top 64 varying key bits as at most six runs.  A mask in more pieces (few distinct values in a field leave
+// scattered bits) has its closest runs joined across the constant bits between them -- those cost width, not order --
+// and what then exceeds 64 bits loses its low end: ties, which go to the same leaf.
 SqueezeSpec make_squeeze(const uint32_t vary[3], uint32_t total_bits) {
-    SqueezeSpec sq{};
     auto varies = [&](int b) { return ((vary[b >> 5] >> (b & 31)) & 1u) != 0; };
-    uint32_t have = 0;
-    int b = (int)total_bits - 1;
-    while (b >= 0 && have < 64 && sq.n < 6) {
+    struct Run { int lo, hi; };                  // bits [lo, hi], top run first
+    Run runs[96];
+    int n = 0;
+    for (int b = (int)total_bits - 1; b >= 0;) {
         if (!varies(b)) { --b; continue; }
-        const int top = b;
-        while (b > 0 && varies(b - 1) && (uint32_t)(top - b + 1) + have < 64) --b;
-        const uint32_t w = (uint32_t)(top - b + 1);
-        sq.lo[sq.n] = (uint32_t)b;
+        const int hi = b;
+        while (b > 0 && varies(b - 1)) --b;
+        runs[n++] = Run{b, hi};
+        --b;
+    }
+    while (n > 6) {                              // join the two neighbours with the fewest constant bits between them
+        int best = 0, gap = 1 << 30;
+        for (int i = 0; i + 1 < n; ++i) {
+            const int g = runs[i].lo - runs[i + 1].hi - 1;
+            if (g < gap) { gap = g; best = i; }
+        }
+        runs[best].lo = runs[best + 1].lo;
+        for (int i = best + 1; i + 1 < n; ++i) runs[i] = runs[i + 1];
+        --n;
+    }
+    SqueezeSpec sq{};
+    uint32_t have = 0;
+    for (int i = 0; i < n && have < 64; ++i) {
+        uint32_t w = (uint32_t)(runs[i].hi - runs[i].lo + 1);
+        uint32_t lo = (uint32_t)runs[i].lo;
+        if (have + w > 64) { lo += have + w - 64; w = 64 - have; }     // keep the run's top bits
+        sq.lo[sq.n] = lo;
         sq.w[sq.n] = w;
         ++sq.n;
         have += w;
-        --b;
     }
     uint32_t used = 0;
     for (uint32_t r = 0; r < sq.n; ++r) {
@@ -676,7 +715,10 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
         return hipGetLastError();
     }
     const SqueezeSpec sq = make_squeeze(vary, kl.total_bits);
-    const uint64_t k_target = std::max<uint64_t>(1, ipx_div_up(n, BS_LEAF_AVG));
+    // IPX_BSORT_LEAF_AVG: records per leaf aimed at (tests: a huge value makes one leaf of everything -> overflow)
+    const char *avg_e = getenv("IPX_BSORT_LEAF_AVG");
+    const uint64_t leaf_avg = avg_e && atoll(avg_e) > 0 ? (uint64_t)atoll(avg_e) : BS_LEAF_AVG;
+    const uint64_t k_target = std::min<uint64_t>(std::max<uint64_t>(1, ipx_div_up(n, leaf_avg)), BS_MAX_LEAVES);
     const uint32_t m2 = (uint32_t)std::min<uint64_t>(n, k_target * BS_OVERSAMPLE);
     // coarse ranges: ~1800 second-level sample keys each (a range that draws 1.6 x its share still fits its list),
     // and few enough leaves per range that an uneven range stays below 256

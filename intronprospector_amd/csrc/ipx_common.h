@@ -103,6 +103,11 @@ struct ScanParams {
     // pass the filter against its junction's motif (looked up here, per record); records that fail stay single,
     // because the reduce drops those that precede the junction's creator one by one
     uint32_t combine;
+    // 0: every tile combines.  15: only tiles whose number is a multiple of 16 do -- a PROBE.  Input in random order
+    // finds next to nothing to merge (S shuffled: 5 %) and paid a tenth of its step for the attempt; ipx_push_batch
+    // switches a handle to probing when a batch merged less than a tenth of its records and back when the probe
+    // tiles merge a quarter of theirs (the reference reads unsorted input too: intronProspector.cc:375-387).
+    uint32_t combine_mask;
     int32_t skip_missing;
     // the key rank of a tid is the tid itself (IPX_SCOPE_TARGET): the scan then skips the dependent load of
     // rank_of_tid[tid], one round trip per tile of short reads

@@ -1217,6 +1217,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         unsigned long long my_err = IPX_ERRW_NONE;
         if (t == 0) { pool_n = 0; cx_n = 0; }
         __syncthreads();
+        // does THIS tile combine?  (ScanParams::combine_mask: a launch that only probes combines one tile in sixteen)
+        const uint32_t comb = (p.combine_mask && ((uint32_t)tile & p.combine_mask)) ? 0u : p.combine;
         // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one; see the
         // comments inside.  final_pass: survivors go to the record arrays; else they close ranks inside the pool so
         // that the tile can go on filling it (recombine: the pool may hold records an earlier pass made of several).
@@ -1523,7 +1525,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             // A tile of mostly two-junction reads emits more than the pool holds (S: 3 % of the tiles, a quarter of
             // all records that left the scan uncombined through the second stage).  If the first half of the tile
             // filled more than its share, fold what is there and go on in the room that makes.
-            if (r + 1 < RPT && p.combine) {
+            if (r + 1 < RPT && comb) {
                 __syncthreads();
                 const uint32_t filled = pool_n;
                 if (2u * filled + 64u > POOL && filled <= POOL) {
@@ -1537,7 +1539,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         // Phase 2: the listed alignments, 64 per wave
         const uint32_t n_walk = cx_n;
         // (room for their records -- up to three from eight ops -- if the closed forms nearly filled the pool)
-        if (p.combine && n_walk) {
+        if (comb && n_walk) {
             const uint32_t filled = pool_n;
             if (filled + 3u * n_walk > POOL && filled <= POOL && filled > POOL / 2) {
                 combine_pool(filled, false, recombined);
@@ -1689,7 +1691,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         __syncthreads();
         const uint32_t total = pool_n;
         IPX_ST_LAP(2);                      // phase 2: walks
-        if (total <= POOL && !p.combine) {
+        if (total <= POOL && !comb) {
             if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;

@@ -1,5 +1,5 @@
 """GPU parity for the two sorts of ipx_finalize: the bucket sort (csrc/ipx_bsort.hip: sampled splitters, two radix
-passes on a 16-bit leaf id, every leaf sorted in LDS) takes tables from 4 M records on, the LSD radix sort
+passes on a 16-bit leaf id, every leaf sorted in LDS) takes tables from 16 M records on, the LSD radix sort
 (csrc/ipx_sort.hip) the rest and the bucket sort's overflow cases.  IPX_BSORT_MIN / IPX_SORT force either on any size.
 Every case compares the whole device table with the oracle's (std::map order, junctions.hh:77-100)."""
 import numpy as np
@@ -74,17 +74,66 @@ def test_bucket_sort_on_a_million_records(monkeypatch):
 
 
 def test_leaf_overflow_falls_back_to_the_radix_passes(monkeypatch, capfd):
-    """Unsorted copies of a few keys, the combiner off: one key has more copies than a leaf holds, the bucket sort
-    raises its overflow flag and the LSD sort redoes the table."""
+    """A leaf that does not fit LDS (here: IPX_BSORT_LEAF_AVG makes one leaf of the whole table) raises the overflow
+    flag and the LSD sort redoes the table; the handle then skips the bucket sort for its next finalizes."""
     from intronprospector_amd import synth
     monkeypatch.setenv("IPX_BSORT_MIN", "1")
-    monkeypatch.setenv("IPX_COMBINE", "0")
+    monkeypatch.setenv("IPX_BSORT_LEAF_AVG", "1000000000")
     monkeypatch.setenv("IPX_DEBUG_PLAN", "1")
-    batch, names, _ = synth.short_reads(200_000, seed=70, n_targets=2, target_len=4_000_000, n_sites=3)
+    batch, names, _ = synth.short_reads(200_000, seed=70, n_targets=2, target_len=4_000_000, n_sites=3000)
     dev, ora, err = _run_both(batch, names, {})
     assert err is None
     helpers.compare_tables(dev, ora)
     assert "bucket sort overflowed" in capfd.readouterr().err
+
+
+def test_keys_with_thousands_of_copies_get_leaves_of_their_own(monkeypatch, capfd):
+    """Unsorted copies of a few keys, the combiner off: a key drawn as two splitters in a row is fenced into a leaf
+    of its own (k_bs_sort2), which may be of any size because its keys are all equal."""
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_BSORT_MIN", "1")
+    monkeypatch.setenv("IPX_COMBINE", "0")
+    monkeypatch.setenv("IPX_DEBUG_PLAN", "1")
+    batch, names, _ = synth.short_reads(2_000_000, seed=71, n_targets=2, target_len=4_000_000, n_sites=40)
+    rng = np.random.default_rng(6)
+    shuffled = synth.permute_batch(batch, rng.permutation(len(batch["tid"])))
+    dev, ora, err = _run_both(shuffled, names, {})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+    assert "bucket sort overflowed" not in capfd.readouterr().err
+
+
+def test_combiner_probes_when_the_input_is_unsorted(monkeypatch, capfd):
+    """sorted batch, shuffled batch, shuffled batch, sorted batch, sorted batch in ONE table: after a batch that merged
+    next to nothing only one tile in sixteen still combines, and the full combiner returns when the probe tiles
+    merge again (ScanParams::combine_mask); the table is the oracle's either way, and the same with the adaption off"""
+    from intronprospector_amd import synth
+    import intronprospector_amd as ipa
+    from tests.oracle_binding import Oracle
+    monkeypatch.setenv("IPX_DEBUG_PLAN", "1")
+    parts = []
+    for k, shuffle in enumerate((False, True, True, False, False)):
+        b, names, _ = synth.short_reads(300_000, seed=90 + k, n_targets=3, target_len=5_000_000, n_sites=4000)
+        if shuffle:
+            b = synth.permute_batch(b, np.random.default_rng(k).permutation(len(b["tid"])))
+        parts.append(b)
+    whole = synth.concat_batches(parts)
+    ora = Oracle(targets=names)
+    ora.process(whole)
+    tab = ora.table()
+    ora.close()
+    for adapt in ("1", "0"):
+        monkeypatch.setenv("IPX_COMBINE_ADAPT", adapt)
+        ex = ipa.JunctionsExtractor(targets=names)
+        for b in parts:
+            ex.push(b)
+        dev = ex.get_junctions()
+        ex.close()
+        helpers.compare_tables(dev, tab)
+        lines = [l for l in capfd.readouterr().err.splitlines() if "scan of" in l]
+        assert len(lines) == 5
+        probing = ["probing" in l for l in lines]
+        assert probing == ([False, False, True, True, False] if adapt == "1" else [False] * 5), lines
 
 
 def test_a_table_of_one_key_needs_no_sorting(monkeypatch, capfd):

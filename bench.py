@@ -242,12 +242,28 @@ def upload(batch, dev):
     return arrays, [t.data_ptr() for t in arrays]
 
 
+def kernel_source_hash():
+    """sha256 over the device sources (csrc/*.hip, *.h): what profiles/traffic.json was measured on is stamped with it"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "intronprospector_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(kind):
+    """PMC traffic of the workload from profiles/traffic.json -- only if it was measured on THESE kernel sources
+    (its `kernel_sources_sha16` stamp); a stale file yields nothing and the line says traffic: null"""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tpath)).get(kind, {})
+        doc = json.load(open(tpath))
     except Exception:
         return {}
+    if doc.get("kernel_sources_sha16") != kernel_source_hash():
+        return {"stale": True, "measured_on": doc.get("kernel_sources_sha16")}
+    return doc.get(kind, {})
 
 
 def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, breakdown_steps, steps):
@@ -267,6 +283,9 @@ def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, 
         "traffic_step_bytes": traffic_step,
         "waste_ratio": (traffic_step / alg_step) if traffic_step else None,
         "launches_per_step": tr.get("launches_per_step"),
+        "traffic_source": ("profiles/traffic.json is stale (measured on kernel sources %s, these are %s): traffic not reported"
+                           % (tr.get("measured_on"), kernel_source_hash())) if tr.get("stale") else
+                          "profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on these kernel sources",
         "device_ms_per_step": dev_ms,
         "records_after_combine": m,
     }
@@ -286,25 +305,33 @@ def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, 
     return out
 
 
-def run_single(kind, batch, names, genome, dev, local_rank, steps, warmup, prefix):
-    """one workload on one GPU, no collectives: the `configs` entries"""
+def run_single(kind, batch, names, genome, dev, local_rank, steps, warmup, prefix, extra_batches=()):
+    """one workload on one GPU, no collectives: the `configs` entries.  extra_batches: further batches of the same
+    shape (other seeds); step k then takes batch k mod their number, so that nothing a handle carries from one batch
+    to the next (first-pass digit window, second-stage grid, combiner mode, capacity estimates) is a guaranteed hit"""
     import torch
     import intronprospector_amd as ipa
     from intronprospector_amd import _lib as L
-    n, n_words = len(batch["tid"]), len(batch["cigar"])
-    arrays, ptrs = upload(batch, dev)
+    batches = [batch] + list(extra_batches)
+    n = int(round(sum(len(b["tid"]) for b in batches) / len(batches)))
+    n_words = int(round(sum(len(b["cigar"]) for b in batches) / len(batches)))
+    ups = [upload(b, dev) for b in batches]
+    arrays = [u[0] for u in ups]
+    turn = [0]
     params = _oracle_params(kind)
     pack = None
     if genome is not None:
         pack = (genome.names, [(t, m, len(q)) for (t, m), q in zip(genome.twobit(), genome.seqs)])
         params.update(genome=pack, junction_filter=L.IPX_SJ_CANON)
     ex = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
-    ex.reserve(0, 0, n_words // 2 + 1024)
+    ex.reserve(0, 0, max(len(b["cigar"]) for b in batches) // 2 + 1024)
     table = None
 
     def step():
+        k = turn[0] % len(batches)
+        turn[0] += 1
         ex.clear()
-        ex.push_device(n, n_words, ptrs, base_read_index=0)
+        ex.push_device(len(batches[k]["tid"]), len(batches[k]["cigar"]), ups[k][1], base_read_index=0)
         m = ex.records_pending()
         rc, t = ex.finalize_raw(L.IPX_MEM_DEVICE)
         if rc:
@@ -342,9 +369,89 @@ def run_single(kind, batch, names, genome, dev, local_rank, steps, warmup, prefi
            "frac": roof["frac"], "achieved": roof["achieved"], "kernel": roof.get("kernel"),
            "kernel_frac": roof.get("kernel_frac"), "kernel_avg_ms": roof.get("kernel_avg_ms"),
            "records_after_combine": m, "kernels_ms_per_step": roof.get("kernels_ms_per_step")}
+    if len(batches) > 1:
+        out["rotating"] = "%d batches of other seeds take turns (alignments, CIGAR words: their mean; records: the last step's)" % len(batches)
     if prefix:
         out["parity_prefix"] = parity_prefix(kind, batch, names, pack, genome, prefix, local_rank)
     return out
+
+
+def run_m1(args, local_rank):
+    """One rank's share of config 5 (M = 100 chunks of 10 M alignments, seeds SEED_M0 + i, a contiguous
+    eighth per GPU): chunks 0..12 (the thirteenth half) resident in HBM, a step = ipx_clear + thirteen pushes into
+    ONE table + ipx_finalize.  The whole table is compared with the oracle's of the same stream."""
+    import torch
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth, _lib as L
+    from tests import helpers
+    from tests.oracle_binding import Oracle
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    t_gen = time.perf_counter()
+    ups, sizes, names, ora, t_cpu = [], [], None, None, 0.0
+    for i in range(13):
+        b, names, _ = synth.short_reads(10_000_000 if i < 12 else 5_000_000, seed=synth.SEED_M0 + i)
+        if ora is None:
+            ora = Oracle(targets=names)
+        t0 = time.perf_counter()
+        ora.process(b)
+        t_cpu += time.perf_counter() - t0
+        ups.append(upload(b, dev))
+        sizes.append((len(b["tid"]), len(b["cigar"])))
+        del b
+    t_gen = time.perf_counter() - t_gen
+    n, n_words = sum(a for a, _ in sizes), sum(w for _, w in sizes)
+    ex = ipa.JunctionsExtractor(targets=names, device=local_rank)
+
+    def step():
+        ex.clear()
+        base = 0
+        for (na, nw), (_, ptrs) in zip(sizes, ups):
+            ex.push_device(na, nw, ptrs, base_read_index=base)
+            base += na
+        m = ex.records_pending()
+        rc, t = ex.finalize_raw(L.IPX_MEM_DEVICE)
+        if rc:
+            ex._check(rc)
+        return t, m
+    for _ in range(max(args.warmup, 1)):
+        table, m = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table, m = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ex.profile(True)
+    table, m = step()
+    torch.cuda.synchronize()
+    stats = ex.profile_read()
+    ex.profile(False)
+    r, nj = int(table.n_records), int(table.n_junctions)
+    dev_tab = ex.get_junctions()
+    ex.close()
+    ref = ora.table()
+    ora.close()
+    try:
+        helpers.compare_tables(dev_tab, ref)
+        parity = {"equals_oracle": True, "junctions": int(len(ref["intron_start"])), "alignments": n}
+    except AssertionError as e:
+        parity = {"equals_oracle": False, "error": str(e)[:300]}
+    ms = elapsed / args.steps * 1e3
+    b_alg = 20 + 4 * n_words / n + 64 * r / n
+    return {"metric": "alignments/sec junction extraction", "value": n * args.steps / elapsed, "unit": "alignments/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+            "config": {"workload": "M1: one rank's share of 1 G short reads over 8 GPUs = %d alignments in 13 pushes (chunks of "
+                                   "seeds %d..%d), one table of %d junctions" % (n, synth.SEED_M0, synth.SEED_M0 + 12, nj),
+                       "alignments_per_gpu": n, "cigar_words": n_words, "records": r, "records_after_combine": int(m),
+                       "junctions": nj, "generate_s": t_gen, "parity": parity,
+                       "input": "SoA chunks resident in HBM before the timed region"},
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": b_alg * n / (ms * 1e-3) / 1e9,
+                         "frac": b_alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernels_ms_per_step": {k: v[1] for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])}},
+            "cpu_baseline": {"value": n / t_cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
+                             "sample": "the oracle over the same 125 M alignments, one pass, %.1f s" % t_cpu}}
 
 
 def main():
@@ -352,7 +459,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="S", choices=["S", "L", "G"])
+    ap.add_argument("--workload", default="S", choices=["S", "L", "G", "M1"],
+                    help="M1: ONE rank's share of BASELINE's config 5 (1 G short reads over 8 GPUs): 125 M alignments, "
+                         "chunks 0..12 of the M workload pushed into one table, whole table against the oracle")
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10 M for S and G, 2 M for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -385,6 +494,12 @@ def main():
     import torch            # before the package: libipx.so must bind to the HIP runtime torch brings along
     from intronprospector_amd import synth
     kind = args.workload
+    if kind == "M1":
+        out = run_m1(args, local_rank)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+        return
     reads = args.reads or DEFAULT_READS[kind]
     seed = (synth.SEED_L if kind == "L" else synth.SEED_S) if world == 1 else synth.SEED_M0 + rank
     t_gen = time.perf_counter()
@@ -555,6 +670,19 @@ def main():
                 del b2, g2
             except Exception as e:                   # the headline line must still come out
                 configs[k2] = {"error": repr(e)[:300]}
+        # the headline workload again, three batches of different seeds taking turns: what the per-handle hints cost
+        # when they miss (the headline replays ONE batch, so every hint is a hit)
+        t1 = time.perf_counter()
+        try:
+            bs = [make_workload("S", DEFAULT_READS["S"], synth.SEED_S + k)[0] for k in range(3)]
+            gen_s = time.perf_counter() - t1
+            rec = run_single("S", bs[0], names, None, dev, local_rank, 12, 3, 0, extra_batches=bs[1:])
+            rec["generate_s"] = gen_s
+            rec["seeds"] = [synth.SEED_S + k for k in range(3)]
+            configs["S_rotating"] = rec
+            del bs
+        except Exception as e:
+            configs["S_rotating"] = {"error": repr(e)[:300]}
         out["configs"] = configs
     if multi:
         dist.destroy_process_group()

@@ -18,6 +18,7 @@ import sys
 CLASS = [
     (r"k_scan_short|k_scan_long|k_scan_rest|k_scan_ops|k_close_|k_cigar_tail", "k_scan"),
     (r"k_scatter", "k_scatter"), (r"k_hist", "k_hist"), (r"k_binscan", "k_binscan"),
+    (r"k_bs_leaf", "k_bs_leaf"), (r"k_bs_assign", "k_bs_assign"), (r"k_bs_sample|k_bs_sort2", "k_bs_sample"), (r"k_bs_bounds", "k_bs_bounds"),
     (r"k_reduce<1>", "k_reduce_a"), (r"k_reduce", "k_reduce"),
     (r"k_count_heads", "k_count_heads"), (r"k_write_heads|k_init_rows", "k_write_heads"),
     (r"k_scan_sums|k_scan_top|k_scan_apply|k_scan_small", "scan_u32"),
@@ -69,6 +70,15 @@ def main():
         t = json.load(open(path))
     except Exception:
         t = {}
+    # the kernel sources these counters were measured on: bench.py reports the traffic only while they are unchanged.
+    # A file measured on other sources is started afresh (workloads measured on different builds must not mix).
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+    stamp = kernel_source_hash()
+    if t.get("kernel_sources_sha16") != stamp:
+        t = {}
+    t["kernel_sources_sha16"] = stamp
     t[wl] = out
     t.setdefault("detail", {})[wl] = detail
     t["note"] = ("bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; FETCH doubled per MI355X_MICROARCH.md, gfx950), L2 <-> fabric "

@@ -121,3 +121,32 @@ def test_config_G_genome_strand_inference(tmp_path):
         return bytes([s[start], s[start + 1], s[end - 2], s[end - 1]])
     helpers.compare_tables(t1, ora.table(), fetch)
     ora.close()
+
+
+def test_config_M_one_rank_share_125M_alignments():
+    """BASELINE.json's config 5 (1 G short reads over 8 GPUs) as ONE rank sees it: 125 M alignments -- chunks 0..12 of
+    the M workload (seeds SEED_M0 + i, 10 M alignments each, the thirteenth half) -- pushed chunk by chunk into one
+    table (whole-run scope, thirteen pushes, 26 M combined records, the bucket sort's scale) and compared with the
+    oracle's table of the same stream, junction by junction.  Chunks are generated, pushed and dropped one at a time."""
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    ex = ora = None
+    total = 0
+    for i in range(13):
+        n = 10_000_000 if i < 12 else 5_000_000
+        batch, names, _ = synth.short_reads(n, seed=synth.SEED_M0 + i)
+        if ex is None:
+            ex = ipa.JunctionsExtractor(targets=names)
+            ora = Oracle(targets=names)
+        ex.push(batch)
+        ora.process(batch)
+        total += n
+        del batch
+    dev = ex.get_junctions()
+    ex.close()
+    tab = ora.table()
+    ora.close()
+    assert dev["n_alignments"] == total == 125_000_000
+    assert len(dev["intron_start"]) > 3_000_000 and dev["n_records"] > 100_000_000
+    helpers.compare_tables(dev, tab)
+    _check_properties(dev, total)

@@ -562,7 +562,14 @@ def main():
         n_items[0] = ex.records_pending()
         if exchanger is not None:
             # junction records -> key-range owners over RCCL (all_to_all), then the local finalize
-            table, ijunc = exchanger.run(ex, n)
+            from intronprospector_amd.distributed import SlotOverflow
+            while True:
+                try:
+                    table, ijunc = exchanger.run(ex, n)
+                    break
+                except SlotOverflow:              # (sizes come from the batch before; a larger batch is scanned again)
+                    ex.clear()
+                    ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
             n_records[0] = table.n_records
             n_merged[0] = int(table.n_junctions)          # this rank's key range; summed after the timed loop
             return table

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IPX_ABI_VERSION 2
+#define IPX_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -320,6 +320,36 @@ int ipx_records_partition(ipx_handle *h, uint32_t n_parts, const uint64_t *split
                           void *dst_records);
 int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n_alignments);
 
+/* The same exchange without a host in the loop (ABI 3): parts go to fixed-capacity SLOTS of slot_records 32-byte
+ * records each, slot p at dst_slots + p * slot_records * 32.  A slot begins with a header of 1 + (n_parts + 7) / 8
+ * records written on the device -- the part's true count, the sender's largest part, a flag "some part of this sender did not fit its slot", and the
+ * sender's own error (error_order = ipx_error.order of what this rank found wrong with its input, ~0 if nothing;
+ * error_status its ipx status) -- so one all-to-all with EQUAL splits carries everything the receivers need:
+ *   ipx_records_partition_slots  queues the kernels and returns (no read-back); dst_slots: device memory, n_parts slots
+ *   ipx_records_adopt_slots      n_slots received slots -> the handle's pending records; info: what the headers said.
+ *                                info->overflow != 0: some part somewhere was cut short -- the table would be wrong;
+ *                                repeat scan + exchange with slots of more than info->max_part records.
+ *                                info->error_order != ~0: sender info->error_slot reported the earliest error of the run
+ * Both take the handle's stream: with ipx_use_stream the caller's collective needs no host synchronisation between. */
+typedef struct ipx_slots_info {
+    uint64_t n_records;      /* adopted */
+    uint64_t max_part;       /* the largest part any sender had for any receiver */
+    uint32_t overflow;
+    uint32_t error_slot;
+    uint64_t error_order;
+    int32_t error_status;
+    int32_t reserved;
+    uint64_t max_received;   /* records the busiest rank receives, and what all ranks receive together: the same */
+    uint64_t all_received;   /* numbers on every rank (every header carries its sender's counts for all parts) */
+} ipx_slots_info;
+int ipx_records_partition_slots(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t slot_records,
+                                uint64_t error_order, int32_t error_status, void *dst_slots);
+int ipx_records_adopt_slots(ipx_handle *h, uint32_t n_slots, uint64_t slot_records, const void *slots,
+                            uint64_t n_alignments, ipx_slots_info *info);
+/* Run everything the handle queues on the caller's HIP stream (hipStream_t; NULL: back to the handle's own), e.g. the
+ * stream a torch.distributed collective is ordered on.  Waits for what the handle had queued before. */
+int ipx_use_stream(ipx_handle *h, void *hip_stream);
+
 /* The handle's pending junction records, decoded, in no particular order (sort by `order`
  * for the order in which the reference would have met them).  For --debug-trace
  * (src/junctions_extractor.cc:451-457,471-477): the trace is the list of records that a
@@ -366,6 +396,8 @@ int ipx_group_uses_rccl(const ipx_group *g);
 
 /* copy between any two of {host, device} on the handle's stream, then wait */
 int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes);
+/* the same without the wait (stream-ordered; the source must stay valid until the stream gets there) */
+int ipx_copy_async(ipx_handle *h, void *dst, const void *src, uint64_t bytes);
 
 /* device timing of the last ipx_push_batch / ipx_finalize in milliseconds,
  * measured with HIP events on the handle's stream */

@@ -30,6 +30,7 @@ SYMBOLS = [
     "ipx_group_last_error", "ipx_group_uses_rccl",
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
     "ipx_push_bam", "ipx_push_bam_async", "ipx_bgzf_inflate",
+    "ipx_records_partition_slots", "ipx_records_adopt_slots", "ipx_use_stream", "ipx_copy_async",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -80,6 +81,12 @@ class Error(C.Structure):
     ]
 
 
+class SlotsInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("max_part", C.c_uint64), ("overflow", C.c_uint32), ("error_slot", C.c_uint32),
+                ("error_order", C.c_uint64), ("error_status", C.c_int32), ("reserved", C.c_int32),
+                ("max_received", C.c_uint64), ("all_received", C.c_uint64)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -123,6 +130,10 @@ def load():
     lib.ipx_records_sample.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.ipx_records_partition.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     lib.ipx_records_adopt.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
+    lib.ipx_records_partition_slots.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int32, vp]
+    lib.ipx_records_adopt_slots.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64, C.POINTER(SlotsInfo)]
+    lib.ipx_use_stream.argtypes = [vp, vp]
+    lib.ipx_copy_async.argtypes = [vp, vp, vp, C.c_uint64]
     lib.ipx_records_export.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ipx_profile.argtypes = [vp, C.c_int]

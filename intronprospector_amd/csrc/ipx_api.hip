@@ -111,7 +111,8 @@ struct PendingPush {
 struct ipx_handle {
     ipx_params params{};
     Profiler prof;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where everything is queued: the handle's own stream, or the caller's (ipx_use_stream)
+    hipStream_t own_stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // targets
     std::vector<std::string> names;
@@ -131,6 +132,9 @@ struct ipx_handle {
     bool opt_combine = true;       // IPX_OPT_COMBINE: the short-read scan may merge equal-key records of a tile
     bool comb_probe = false;       // the last batch found too little to merge: only every sixteenth tile still tries
     uint32_t bsort_skip = 0;       // finalizes that go straight to the radix passes after the bucket sort overflowed
+    unsigned long long spl_host[64] = {};      // the splitters the device copy holds (ipx_records_partition_slots)
+    bool spl_valid = false;
+    void *spl_where = nullptr;
     uint64_t n_raw = 0;            // junction records that passed junction_qc (>= n_records once records were combined)
     uint32_t key_or[3] = {0, 0, 0}, key_and[3] = {~0u, ~0u, ~0u};   // host copy of Counters::key_or/and
     uint64_t rec_cap = 0, n_records = 0, n_alignments = 0;
@@ -453,7 +457,8 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
         const char *e = getenv("IPX_SCAN");
         h->force_lane_scan = !(e && strcmp(e, "ops") == 0);
     }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
+    h->stream = h->own_stream;
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
     if (hipHostMalloc(&h->pin_small, 4096, hipHostMallocDefault) != hipSuccess) { ipx_destroy(h); return IPX_ENOMEM; }
@@ -492,7 +497,7 @@ int ipx_destroy(ipx_handle *h) {
     if (h->pin_out2) (void)hipHostFree(h->pin_out2);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return IPX_OK;
 }
@@ -1437,6 +1442,109 @@ int ipx_records_adopt(ipx_handle *h, uint64_t n, const void *records, uint64_t n
     for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
     h->n_records = n;
     h->n_raw = n + ((uint64_t)m2[0] | ((uint64_t)m2[1] << 32));
+    h->n_alignments = n_alignments;
+    return IPX_OK;
+}
+
+int ipx_use_stream(ipx_handle *h, void *hip_stream) {
+    if (!h) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return IPX_OK;
+}
+
+int ipx_copy_async(ipx_handle *h, void *dst, const void *src, uint64_t bytes) {
+    if (!h || (bytes && (!dst || !src))) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    if (!bytes) return IPX_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+    return IPX_OK;
+}
+
+// the splitters as the partition kernels want them (device copy, refreshed when they change)
+static int stage_splitters(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, unsigned long long **d_spl,
+                           unsigned long long **d_cnt, unsigned long long **d_blk, uint32_t blocks) {
+    int rc = ensure(h, h->d_xchg, ((size_t)4096 + 2 * 64 + (size_t)blocks * 64) * 8);
+    if (rc) return rc;
+    *d_spl = h->d_xchg.as<unsigned long long>() + 4096;
+    *d_cnt = *d_spl + 64;
+    *d_blk = *d_cnt + 64;
+    unsigned long long host[64];
+    memset(host, 0, sizeof host);
+    for (uint32_t i = 0; i + 1 < n_parts; ++i) host[i] = splitters[i];
+    if (h->spl_valid && h->d_xchg.p == h->spl_where && memcmp(host, h->spl_host, sizeof host) == 0) return IPX_OK;
+    // (a copy from this stack frame: staged by the runtime before the call returns)
+    HIPCHK(hipMemcpyAsync(*d_spl, host, sizeof host, hipMemcpyHostToDevice, h->stream));
+    memcpy(h->spl_host, host, sizeof host);
+    h->spl_valid = true;
+    h->spl_where = h->d_xchg.p;
+    return IPX_OK;
+}
+
+int ipx_records_partition_slots(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t slot_records,
+                                uint64_t error_order, int32_t error_status, void *dst_slots) {
+    if (!h || !n_parts || n_parts > 64 || (n_parts > 1 && !splitters) || slot_records < 2 + (n_parts + 7) / 8 || !dst_slots) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
+    const uint32_t blocks = ipx_partition_blocks(h->n_records);
+    unsigned long long *d_spl, *d_cnt, *d_blk;
+    int rc = stage_splitters(h, n_parts, splitters, &d_spl, &d_cnt, &d_blk, blocks);
+    if (rc) return rc;
+    ProfScope prof_scope(&h->prof);
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    HIPCHK(ipx_launch_partition_slots(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->n_records,
+                                      h->key, n_parts, d_spl, d_blk, d_cnt, slot_records, error_order, (uint32_t)error_status,
+                                      (uint4 *)dst_slots));
+    return IPX_OK;
+}
+
+int ipx_records_adopt_slots(ipx_handle *h, uint32_t n_slots, uint64_t slot_records, const void *slots, uint64_t n_alignments,
+                            ipx_slots_info *info) {
+    if (!h || !n_slots || n_slots > 64 || slot_records < 2 + (n_slots + 7) / 8 || !slots || !info) return IPX_EINVAL;
+    (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
+    const unsigned long long scan_err = h->err_word_host;       // what this rank's scan found wrong stays (see ipx_records_adopt)
+    h->n_records = 0;
+    h->n_raw = 0;
+    h->digs_stale = false;
+    h->first_window = h->first_hint;
+    for (int k = 0; k < 3; ++k) { h->key_or[k] = 0; h->key_and[k] = ~0u; }
+    Counters c{};
+    c.n_records = 0;
+    c.err_word = scan_err;
+    for (int k = 0; k < 3; ++k) { c.key_or[k] = 0; c.key_and[k] = ~0u; }
+    hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->counters.as<Counters>(), c);
+    HIPCHK(hipGetLastError());
+    int rc;
+    if ((rc = grow_records(h, (uint64_t)n_slots * slot_records + 1))) return rc;
+    ProfScope prof_scope(&h->prof);
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    unsigned long long *merged_dev = reinterpret_cast<unsigned long long *>(h->counters.as<char>() + IPX_CNT_MERGED);
+    HIPCHK(hipMemsetAsync(merged_dev, 0, sizeof(unsigned long long), h->stream));
+    // the headers' summary lands right behind the merged-records counter: one publication brings all of it back
+    uint32_t *d_info = reinterpret_cast<uint32_t *>(h->counters.as<char>() + IPX_CNT_MERGED + 8);
+    HIPCHK(ipx_launch_adopt_slots(h->stream, (const uint4 *)slots, n_slots, slot_records, 0, h->items_a.as<uint4>(), h->pays.as<uint4>(),
+                                  h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>(), d_info));
+    if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, merged_dev, 2 + 13))) return rc;
+    h->prof.collect();
+    const Counters *cc = (const Counters *)h->pin_small;
+    const uint32_t *m2 = (const uint32_t *)h->pin_small + sizeof(Counters) / 4;
+    const unsigned long long merged = (unsigned long long)m2[0] | ((unsigned long long)m2[1] << 32);
+    const uint32_t *w = m2 + 2;
+    for (int k = 0; k < 3; ++k) { h->key_or[k] = cc->key_or[k]; h->key_and[k] = cc->key_and[k]; }
+    info->n_records = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    info->max_part = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    info->overflow = w[4];
+    info->error_slot = w[5];
+    info->error_order = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
+    info->error_status = (int32_t)w[8];
+    info->reserved = 0;
+    info->max_received = (uint64_t)w[9] | ((uint64_t)w[10] << 32);
+    info->all_received = (uint64_t)w[11] | ((uint64_t)w[12] << 32);
+    h->n_records = info->n_records;
+    h->n_raw = info->n_records + merged;
     h->n_alignments = n_alignments;
     return IPX_OK;
 }

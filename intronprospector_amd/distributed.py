@@ -270,6 +270,7 @@ class RecordExchanger:
     # batches from one input keeps its key distribution, so the splitters of the first batch are kept and
     # drawn again only after an exchange in which some rank received more than REBALANCE x the mean.
     REBALANCE = 1.25
+    SLOT_MARGIN = 1.25                   # slots and the order gather: this much above the previous batch's need
 
     def __init__(self, device, group=None, comm_device=None, reuse_splitters=True):
         self.device, self.group = device, group
@@ -280,6 +281,12 @@ class RecordExchanger:
         self.resampled = 0               # how often the splitters were drawn (statistics, tests)
         self.timed = False               # profiles/rehearse_exchange_timing.py: synchronise and time every stage
         self.stage_ms = {}
+        self.slotted = True              # False: always the exact exchange (tests compare both)
+        self._slot_records = None        # records per slot of the slotted exchange (None: not known yet)
+        self._order_cap = None           # creation orders per rank in the fixed-length gather
+        self._order_cap_grown = False
+        self._send = self._recv = None
+        self.slot_overflows = 0
 
     def _lap(self, name, t0):
         import time
@@ -295,7 +302,127 @@ class RecordExchanger:
         return t if t.device == self.comm_device else t.to(self.comm_device)
 
     def run(self, ex, n_alignments_local=0):
-        """-> (ipx_table of this rank's key range, device memory; global ijunc per row as a tensor)."""
+        """-> (ipx_table of this rank's key range, device memory; global ijunc per row as a tensor).
+
+        Two forms.  The EXACT exchange (the first batch, and whenever the splitters were just drawn): the ranks tell
+        each other their per-peer counts, all_to_all with those splits, orders gathered at their true lengths -- five
+        host round trips a step.  The SLOTTED exchange (every later batch): sizes are taken from the batch before
+        with a margin, parts travel in fixed-capacity slots whose headers carry the true counts, an overflow flag and
+        the ranks' errors (ipx_records_partition_slots), so ONE all_to_all with equal splits needs no counts collective
+        and no read-back before it; the creation orders are gathered at a fixed length too.  A batch that outgrows
+        its slots raises SlotOverflow after the sizes were raised: the caller scans the batch again and calls run()
+        once more (nothing of the cut-short exchange is kept)."""
+        if (self._splitters is None or not self.reuse_splitters or self._slot_records is None or not self.slotted
+                or len(self._splitters) != dist.get_world_size(self.group) - 1):
+            return self._run_exact(ex, n_alignments_local)
+        return self._run_slotted(ex, n_alignments_local)
+
+    def _run_slotted(self, ex, n_alignments_local):
+        from . import _lib as L
+        from .extractor import IpxError
+        import time
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        t0 = time.perf_counter()
+        S = self._slot_records
+        failed = None
+        try:
+            ex.records_pending()                  # completes a pending push: a data error of this rank's scan surfaces at finalize
+        except IpxError as exc:
+            failed = ShardError.from_ipx(exc)
+        # everything below is queued on ONE stream -- the handle's kernels, torch's ops, the collectives' waits
+        staged = self.comm_device != self.device          # gloo rehearsal: the collectives run on CPU copies
+        stream = torch.cuda.current_stream(self.device)
+        ex.use_stream(stream.cuda_stream)
+        need = world * S * 32
+        if self._send is None or self._send.numel() < need:
+            self._send = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._recv = torch.empty(need, dtype=torch.uint8, device=self.device)
+        send, recv = self._send[:need], self._recv[:need]
+        try:
+            ex.records_partition_slots(self._splitters, S, send.data_ptr(),
+                                       failed.order if failed else ERR_NONE, failed.status if failed else 0)
+        except IpxError as exc:                  # (arguments, memory: not about the data) -- empty slots that say so
+            failed = ShardError.from_ipx(exc)
+            send.zero_()
+            hdr = torch.tensor([0, 0, 0, 0, 0, failed.status, failed.order & 0xffffffff, failed.order >> 32],
+                               dtype=torch.int64, device=self.device).to(torch.int32).view(torch.uint8)
+            for p in range(world):
+                send[p * S * 32:p * S * 32 + 32] = hdr
+        t0 = self._lap("partition", t0)
+        if staged:
+            recv_c = torch.empty(need, dtype=torch.uint8, device=self.comm_device)
+            dist.all_to_all_single(recv_c, send.to(self.comm_device), group=self.group)
+            recv.copy_(recv_c)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)         # equal splits: no counts, no host
+        t0 = self._lap("all_to_all", t0)
+        info = ex.records_adopt_slots(world, S, recv.data_ptr(), n_alignments_local)
+        t0 = self._lap("adopt", t0)
+        # (what the headers said is the same on every rank -- every sender's flags reach every receiver -- so all
+        # ranks take the same branch here without talking to each other)
+        if info.error_order != ERR_NONE or (failed is not None):
+            ex.use_stream(None)
+            agree_on_error(failed, self.group, self.comm_device)
+        if info.overflow:
+            self._slot_records = int(info.max_part * self.SLOT_MARGIN) + 64
+            self.slot_overflows += 1
+            ex.use_stream(None)
+            raise SlotOverflow(self._slot_records)
+        # keep the slots a margin above what the data needs (they shrink slowly, grow at once)
+        want = int(info.max_part * self.SLOT_MARGIN) + 64
+        self._slot_records = want if want > S else max(want, int(S * 0.9))
+        # the counts rows in the headers are the whole counts matrix: every rank sees the same imbalance
+        if world > 1 and info.max_received > self.REBALANCE * max(info.all_received / world, 1.0):
+            self._splitters = None                                     # draw new splitters next time
+        table = None
+        try:
+            rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
+            if rc:
+                ex._check(rc)
+        except IpxError as exc:
+            failed = ShardError.from_ipx(exc)
+        t0 = self._lap("finalize", t0)
+        # global sjN: creation orders gathered at a fixed length.  (A data error found by this rank's reduce travels
+        # with the length agreement below: every rank takes part in that.)
+        n = int(table.n_junctions) if failed is None else 0
+        J = self._order_cap
+        if J is None or n + 1 > J:
+            J = self._order_cap = int((n + 1) * self.SLOT_MARGIN) + 64
+            self._order_cap_grown = True
+        co = torch.empty(n, dtype=torch.int64, device=self.device)
+        lij = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            ex.copy_async(co.data_ptr(), table.creator_order, n * 8)
+            ex.copy_async(lij.data_ptr(), table.ijunc, n * 4)
+        mine = torch.full((J,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=self.device)
+        mine[1:n + 1][lij.to(torch.int64)] = co   # scattering by the local rank sorts the orders without a sort
+        # The common length is agreed on with one small all_reduce (a rank whose table outgrew it cannot take part in a
+        # fixed-length gather): [somebody's length changed, the longest length asked for].  Its result is read on the
+        # host -- the one read-back of this stage, of two words, after everything else of the step has been queued
+        cd = self.comm_device
+        flag = torch.tensor([1 if self._order_cap_grown else 0, J, 1 if failed is not None else 0], dtype=torch.int64, device=cd)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        fl = flag.cpu().tolist()
+        self._order_cap_grown = False
+        if fl[2]:                                 # some rank's finalize failed: everybody raises the earliest error
+            ex.use_stream(None)
+            agree_on_error(failed, self.group, self.comm_device)
+        if int(fl[1]) != J:
+            J2 = int(fl[1])
+            self._order_cap = J2
+            pad = torch.full((J2,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=self.device)
+            pad[:n + 1] = mine[:n + 1]
+            mine, J = pad, J2
+        parts = torch.empty((world, J), dtype=torch.int64, device=cd)
+        dist.all_gather_into_tensor(parts.view(-1), mine.to(cd), group=self.group)
+        parts = parts.to(self.device)
+        ijunc = torch.searchsorted(parts[:, 1:].contiguous(), co.unsqueeze(0).expand(world, -1).contiguous()).sum(dim=0)
+        ex.use_stream(None)
+        t0 = self._lap("global_ijunc", t0)
+        return table, ijunc
+
+    def _run_exact(self, ex, n_alignments_local=0):
         from . import _lib as L
         import numpy as np
         world = dist.get_world_size(self.group)
@@ -343,6 +470,8 @@ class RecordExchanger:
         per_rank = cmat.sum(dim=0).to(torch.float64)                   # records each rank receives
         if world > 1 and float(per_rank.max()) > self.REBALANCE * max(float(per_rank.mean()), 1.0):
             self._splitters = None                                     # draw new splitters next time
+        # the next batches travel in slots sized from this one's largest part
+        self._slot_records = int(int(cmat.max()) * self.SLOT_MARGIN) + 64
         t0 = self._lap("counts", t0)
         send_c = self._to_comm(send[:n_local * 32])
         recv_c = torch.empty(max(n_recv, 1) * 32, dtype=torch.uint8, device=self.comm_device)
@@ -379,12 +508,22 @@ class RecordExchanger:
         co_c = self._to_comm(co)
         # (rows filled up with the largest order: they stay sorted and the filling counts for nobody; one
         # batched search instead of one per rank)
-        parts, _ = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError(),
-                                   pad_value=torch.iinfo(torch.int64).max, stacked=True)
+        parts, sizes = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError(),
+                                       pad_value=torch.iinfo(torch.int64).max, stacked=True)
         ijunc = torch.searchsorted(parts, co_c.unsqueeze(0).expand(parts.shape[0], -1).contiguous()).sum(dim=0)
+        self._order_cap = int((max(sizes) + 1) * self.SLOT_MARGIN) + 64
+        self._order_cap_grown = False
         t0 = self._lap("global_ijunc", t0)
         self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
         return table, ijunc
+
+
+class SlotOverflow(Exception):
+    """A part did not fit its slot: scan the batch again and call RecordExchanger.run once more (the slots are larger now)."""
+
+    def __init__(self, slot_records):
+        super().__init__("record exchange: a part outgrew its slot; slots raised to %d records" % slot_records)
+        self.slot_records = slot_records
 
 
 class TableMerger:

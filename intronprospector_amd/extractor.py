@@ -156,6 +156,26 @@ class JunctionsExtractor:
     def records_adopt(self, n, src_ptr, n_alignments=0):
         self._check(self.lib.ipx_records_adopt(self.h, n, src_ptr, n_alignments))
 
+    def records_partition_slots(self, splitters, slot_records, dst_ptr, error_order=(1 << 64) - 1, error_status=0):
+        """The pending records into len(splitters) + 1 slots of slot_records 32-byte records each (the first is the
+        slot's header) at dst_ptr (device); queued on the handle's stream, nothing read back."""
+        spl = np.ascontiguousarray(splitters, np.uint64)
+        self._check(self.lib.ipx_records_partition_slots(self.h, len(spl) + 1, spl.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                         int(slot_records), int(error_order), int(error_status), dst_ptr))
+
+    def records_adopt_slots(self, n_slots, slot_records, src_ptr, n_alignments=0):
+        """-> SlotsInfo: records adopted, the largest part any sender had, overflow, the earliest sender-side error"""
+        info = L.SlotsInfo()
+        self._check(self.lib.ipx_records_adopt_slots(self.h, int(n_slots), int(slot_records), src_ptr, int(n_alignments), C.byref(info)))
+        return info
+
+    def use_stream(self, stream_ptr):
+        """queue everything on the caller's HIP stream (0 / None: the handle's own again)"""
+        self._check(self.lib.ipx_use_stream(self.h, stream_ptr or None))
+
+    def copy_async(self, dst_ptr, src_ptr, n_bytes):
+        self._check(self.lib.ipx_copy_async(self.h, dst_ptr, src_ptr, int(n_bytes)))
+
     def finalize_raw(self, memory=L.IPX_MEM_HOST):
         t = L.Table()
         rc = self.lib.ipx_finalize(self.h, memory, C.byref(t))

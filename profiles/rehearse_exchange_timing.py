@@ -13,8 +13,9 @@ keys = ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")
 arrs = [torch.from_numpy(batch[k]).to(dev) for k in keys]; ptrs = [t.data_ptr() for t in arrs]
 n = len(batch["tid"]); nw = len(batch["cigar"])
 ex = ipa.JunctionsExtractor(targets=names, device=0); ex.reserve(0, 0, nw // 2 + 1024)
-for reuse in (True, False):
+for reuse, slotted in ((True, True), (True, False), (False, False)):
     X = distributed.RecordExchanger(dev, comm_device=dev, reuse_splitters=reuse)
+    X.slotted = slotted
     def step():
         t = time.perf_counter()
         ex.clear(); ex.push_device(n, nw, ptrs, base_read_index=0)
@@ -27,5 +28,12 @@ for reuse in (True, False):
     push = sum(step() for _ in range(10)) / 10
     out = {"clear+push": round(push, 3)}
     out.update({k: round(v / 10, 3) for k, v in X.stage_ms.items()})
-    print(json.dumps({"reuse_splitters": reuse, "stages_ms": out, "total_ms": round(sum(out.values()), 3)}))
+    # untimed form: what a step costs when nothing synchronises between the stages
+    X.timed = False
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20):
+        ex.clear(); ex.push_device(n, nw, ptrs, base_read_index=0); X.run(ex, n)
+    torch.cuda.synchronize()
+    print(json.dumps({"reuse_splitters": reuse, "slotted": slotted, "stages_ms": out, "total_ms": round(sum(out.values()), 3),
+                      "step_ms_untimed": round((time.perf_counter() - t) / 20 * 1e3, 3)}))
 dist.destroy_process_group()

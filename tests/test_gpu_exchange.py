@@ -47,9 +47,15 @@ def _worker(rank, world, port, genome, reuse, q):
             n = len(batch["tid"])
             cuts = np.linspace(0, n, world + 1).astype(int)
             lo, hi = int(cuts[rank]), int(cuts[rank + 1])
-            ex.clear()
-            ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
-            table, ijunc = xch.run(ex, hi - lo)
+            from intronprospector_amd.distributed import SlotOverflow
+            for attempt in range(3):
+                ex.clear()
+                ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
+                try:
+                    table, ijunc = xch.run(ex, hi - lo)
+                    break
+                except SlotOverflow:             # the batch outgrew the slots sized from the one before: scan it again
+                    assert attempt < 2
             t = table_to_torch(ex, table, "cpu")
             t["ijunc"] = ijunc.cpu()
             # gather every rank's rows (rank order = key order)
@@ -93,8 +99,13 @@ def _worker(rank, world, port, genome, reuse, q):
             drawn.append(xch.resampled)
             r4 = one_exchange(b3)
             drawn.append(xch.resampled)
+            # ... and a batch three times the size of anything before outgrows the slots: overflow, larger slots, again
+            over0 = xch.slot_overflows
+            b5, _, _ = synth.short_reads(180_000, seed=44, n_targets=4, target_len=2_800_000, n_sites=700)
+            r5 = one_exchange(b5)
+            r6 = one_exchange(b5)                 # (fits now)
             if rank == 0:
-                out = (out[0] + r2[0] + r3[0] + r4[0], out[1], out[2], drawn, r4[2])
+                out = (out[0] + r2[0] + r3[0] + r4[0] + r5[0] + r6[0], out[1], out[2], drawn, r4[2], xch.slot_overflows - over0)
         ex.close()
         if rank == 0:
             q.put(out)
@@ -112,11 +123,13 @@ def test_record_exchange_two_ranks_equals_single_run(genome, oracle_lib):
 
 def test_record_exchange_keeps_its_splitters_while_balanced(oracle_lib):
     from tests.mp_util import run_workers
-    bad, n, nper, drawn, nper_last = run_workers(_worker, 2, (_free_port(), False, True), timeout=300)
+    bad, n, nper, drawn, nper_last, overflows = run_workers(_worker, 2, (_free_port(), False, True), timeout=300)
     assert not bad, "exchanged tables differ from the single run in: %s" % bad
     # drawn once for the first batch, kept for the second and (still) for the skewed third, drawn again for the fourth
+    # (the second and third batch travel in slots: the imbalance is read off the slot headers, not off a counts collective)
     assert drawn == [1, 1, 1, 2], drawn
     assert min(nper_last) > 0, nper_last
+    assert overflows == 1, overflows
 
 
 def _error_worker(rank, world, port, path, q):
@@ -148,11 +161,18 @@ def _error_worker(rank, world, port, path, q):
             expect = (e.msg, int(e.index))
         lo, hi = int(cuts[rank]), int(cuts[rank + 1])
         ex = ipa.JunctionsExtractor(targets=names)
+        xch = RecordExchanger(torch.device("cuda", 0), comm_device=torch.device("cpu"))
+        if path == "exchange-slotted":            # a clean batch first: the faulty one then travels in slots
+            clean, _, _ = synth.short_reads(40_000, seed=53, n_targets=4, target_len=2_800_000, n_sites=700)
+            ex.push(synth.slice_batch(clean, lo, hi), base_read_index=lo)
+            xch.run(ex, hi - lo)
+            assert xch._slot_records is not None
+            ex.clear()
         ex.push(synth.slice_batch(batch, lo, hi), base_read_index=lo)
         got = None
         try:
-            if path == "exchange":
-                RecordExchanger(torch.device("cuda", 0), comm_device=torch.device("cpu")).run(ex, hi - lo)
+            if path.startswith("exchange"):
+                xch.run(ex, hi - lo)
             else:
                 TableMerger(torch.device("cpu")).merge(ex, lo)
         except IpxError as e:
@@ -166,7 +186,7 @@ def _error_worker(rank, world, port, path, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("path", ["exchange", "tables"])
+@pytest.mark.parametrize("path", ["exchange", "exchange-slotted", "tables"])
 def test_two_ranks_raise_the_earliest_error_of_the_run(path, oracle_lib):
     from tests.mp_util import run_workers
     everybody, expect, i0, i1 = run_workers(_error_worker, 2, (_free_port(), path), timeout=240)

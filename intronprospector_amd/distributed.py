@@ -19,6 +19,8 @@ whose max-of-confidences rule differs from a single run over the same input.
 Everything here is plumbing on tables of at most a few million rows; torch ops
 are used so the same code runs on CPU tensors under gloo.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -283,10 +285,10 @@ class RecordExchanger:
         self.stage_ms = {}
         self.slotted = True              # False: always the exact exchange (tests compare both)
         self._slot_records = None        # records per slot of the slotted exchange (None: not known yet)
-        self._order_cap = None           # creation orders per rank in the fixed-length gather
-        self._order_cap_grown = False
         self._send = self._recv = None
         self.slot_overflows = 0
+        self.strict = True               # look at the ranks' finalize errors at the end of every run (False: check_last())
+        self._last_trouble = None
 
     def _lap(self, name, t0):
         import time
@@ -315,7 +317,20 @@ class RecordExchanger:
         if (self._splitters is None or not self.reuse_splitters or self._slot_records is None or not self.slotted
                 or len(self._splitters) != dist.get_world_size(self.group) - 1):
             return self._run_exact(ex, n_alignments_local)
+        if os.environ.get("IPX_DEBUG_PLAN"):
+            import sys
+            print("ipx: exchange in slots of %d records" % self._slot_records, file=sys.stderr)
         return self._run_slotted(ex, n_alignments_local)
+
+    def check_last(self):
+        """Did some rank's finalize fail in the last slotted run?  Then every rank raises the earliest error of the run
+        (one small read-back; with strict = False the caller decides when to pay for it)."""
+        if self._last_trouble is None:
+            return
+        worst, failed = self._last_trouble
+        self._last_trouble = None
+        if int(worst.item()) != torch.iinfo(torch.int64).max:
+            agree_on_error(failed, self.group, self.comm_device)
 
     def _run_slotted(self, ex, n_alignments_local):
         from . import _lib as L
@@ -383,41 +398,30 @@ class RecordExchanger:
         except IpxError as exc:
             failed = ShardError.from_ipx(exc)
         t0 = self._lap("finalize", t0)
-        # global sjN: creation orders gathered at a fixed length.  (A data error found by this rank's reduce travels
-        # with the length agreement below: every rank takes part in that.)
+        # global sjN: creation orders gathered at a length every rank derives from the slot headers alone -- a table has
+        # at most as many junctions as its rank received records, and the most any rank received is the same number
+        # everywhere (info.max_received) -- so no lengths are exchanged.  Element 0 carries this rank's own trouble (a
+        # data error its reduce found: the order of that error, else "none"); it is looked at after everything else of
+        # the step has been queued (strict) or by the caller, later (check_last()).
         n = int(table.n_junctions) if failed is None else 0
-        J = self._order_cap
-        if J is None or n + 1 > J:
-            J = self._order_cap = int((n + 1) * self.SLOT_MARGIN) + 64
-            self._order_cap_grown = True
+        J = int(info.max_received) + 1
+        cd = self.comm_device
         co = torch.empty(n, dtype=torch.int64, device=self.device)
         lij = torch.empty(n, dtype=torch.int32, device=self.device)
         if n:
             ex.copy_async(co.data_ptr(), table.creator_order, n * 8)
             ex.copy_async(lij.data_ptr(), table.ijunc, n * 4)
         mine = torch.full((J,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=self.device)
+        if failed is not None:
+            mine[0] = min(failed.order, (1 << 62))
         mine[1:n + 1][lij.to(torch.int64)] = co   # scattering by the local rank sorts the orders without a sort
-        # The common length is agreed on with one small all_reduce (a rank whose table outgrew it cannot take part in a
-        # fixed-length gather): [somebody's length changed, the longest length asked for].  Its result is read on the
-        # host -- the one read-back of this stage, of two words, after everything else of the step has been queued
-        cd = self.comm_device
-        flag = torch.tensor([1 if self._order_cap_grown else 0, J, 1 if failed is not None else 0], dtype=torch.int64, device=cd)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        fl = flag.cpu().tolist()
-        self._order_cap_grown = False
-        if fl[2]:                                 # some rank's finalize failed: everybody raises the earliest error
-            ex.use_stream(None)
-            agree_on_error(failed, self.group, self.comm_device)
-        if int(fl[1]) != J:
-            J2 = int(fl[1])
-            self._order_cap = J2
-            pad = torch.full((J2,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=self.device)
-            pad[:n + 1] = mine[:n + 1]
-            mine, J = pad, J2
         parts = torch.empty((world, J), dtype=torch.int64, device=cd)
         dist.all_gather_into_tensor(parts.view(-1), mine.to(cd), group=self.group)
         parts = parts.to(self.device)
         ijunc = torch.searchsorted(parts[:, 1:].contiguous(), co.unsqueeze(0).expand(world, -1).contiguous()).sum(dim=0)
+        self._last_trouble = (parts[:, 0].min(), failed)
+        if self.strict:
+            self.check_last()
         ex.use_stream(None)
         t0 = self._lap("global_ijunc", t0)
         return table, ijunc
@@ -508,11 +512,9 @@ class RecordExchanger:
         co_c = self._to_comm(co)
         # (rows filled up with the largest order: they stay sorted and the filling counts for nobody; one
         # batched search instead of one per rank)
-        parts, sizes = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError(),
+        parts, _ = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError(),
                                        pad_value=torch.iinfo(torch.int64).max, stacked=True)
         ijunc = torch.searchsorted(parts, co_c.unsqueeze(0).expand(parts.shape[0], -1).contiguous()).sum(dim=0)
-        self._order_cap = int((max(sizes) + 1) * self.SLOT_MARGIN) + 64
-        self._order_cap_grown = False
         t0 = self._lap("global_ijunc", t0)
         self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
         return table, ijunc

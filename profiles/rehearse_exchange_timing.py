@@ -16,6 +16,7 @@ ex = ipa.JunctionsExtractor(targets=names, device=0); ex.reserve(0, 0, nw // 2 +
 for reuse, slotted in ((True, True), (True, False), (False, False)):
     X = distributed.RecordExchanger(dev, comm_device=dev, reuse_splitters=reuse)
     X.slotted = slotted
+    X.strict = False
     def step():
         t = time.perf_counter()
         ex.clear(); ex.push_device(n, nw, ptrs, base_read_index=0)

@@ -99,13 +99,17 @@ def _worker(rank, world, port, genome, reuse, q):
             drawn.append(xch.resampled)
             r4 = one_exchange(b3)
             drawn.append(xch.resampled)
-            # ... and a batch three times the size of anything before outgrows the slots: overflow, larger slots, again
+            # ... and a batch far larger than the one before outgrows the slots sized from that: overflow, larger slots, again
+            r5 = one_exchange(b2)                 # (the skewed batch left no splitters: drawn afresh, exact exchange)
+            r6 = one_exchange(b2)                 # in slots sized from b2
             over0 = xch.slot_overflows
-            b5, _, _ = synth.short_reads(180_000, seed=44, n_targets=4, target_len=2_800_000, n_sites=700)
-            r5 = one_exchange(b5)
-            r6 = one_exchange(b5)                 # (fits now)
+            b7, _, _ = synth.short_reads(600_000, seed=44, n_targets=4, target_len=2_800_000, n_sites=700)
+            r7 = one_exchange(b7)
+            over1 = xch.slot_overflows
+            r8 = one_exchange(b7)                 # (fits now)
             if rank == 0:
-                out = (out[0] + r2[0] + r3[0] + r4[0] + r5[0] + r6[0], out[1], out[2], drawn, r4[2], xch.slot_overflows - over0)
+                out = (out[0] + r2[0] + r3[0] + r4[0] + r5[0] + r6[0] + r7[0] + r8[0], out[1], out[2], drawn, r4[2],
+                       (over1 - over0, xch.slot_overflows - over1))
         ex.close()
         if rank == 0:
             q.put(out)
@@ -129,7 +133,7 @@ def test_record_exchange_keeps_its_splitters_while_balanced(oracle_lib):
     # (the second and third batch travel in slots: the imbalance is read off the slot headers, not off a counts collective)
     assert drawn == [1, 1, 1, 2], drawn
     assert min(nper_last) > 0, nper_last
-    assert overflows == 1, overflows
+    assert overflows == (1, 0), overflows
 
 
 def _error_worker(rank, world, port, path, q):

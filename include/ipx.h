@@ -387,6 +387,9 @@ int ipx_group_set_genome_2bit(ipx_group *g, uint32_t n_seqs, const char *const *
 int ipx_group_set_option(ipx_group *g, int32_t option, int64_t value);
 /* batch in host memory (IPX_MEM_HOST), CIGAR words laid out in alignment order */
 int ipx_group_push_batch(ipx_group *g, const ipx_batch *batch);
+/* one member's share, sharded by the caller; the batch may be in host memory or in THAT member's device memory
+ * (IPX_MEM_DEVICE): the group's steps can then be timed on resident input like a single handle's */
+int ipx_group_push_member(ipx_group *g, uint32_t member, const ipx_batch *batch);
 /* table in host memory, owned by the group, valid until the next finalize / clear / destroy */
 int ipx_group_finalize(ipx_group *g, ipx_table *out);
 int ipx_group_clear(ipx_group *g);

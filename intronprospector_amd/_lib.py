@@ -26,7 +26,7 @@ SYMBOLS = [
     "ipx_records_partition", "ipx_records_adopt", "ipx_records_export", "ipx_last_timing", "ipx_profile",
     "ipx_profile_only", "ipx_profile_read", "ipx_set_option",
     "ipx_group_create", "ipx_group_destroy", "ipx_group_set_targets", "ipx_group_set_genome_2bit",
-    "ipx_group_set_option", "ipx_group_push_batch", "ipx_group_finalize", "ipx_group_clear",
+    "ipx_group_set_option", "ipx_group_push_batch", "ipx_group_push_member", "ipx_group_finalize", "ipx_group_clear",
     "ipx_group_last_error", "ipx_group_uses_rccl",
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
     "ipx_push_bam", "ipx_push_bam_async", "ipx_bgzf_inflate",
@@ -146,6 +146,7 @@ def load():
                                               C.POINTER(vp), C.POINTER(vp)]
     lib.ipx_group_set_option.argtypes = [vp, C.c_int32, C.c_int64]
     lib.ipx_group_push_batch.argtypes = [vp, C.POINTER(Batch)]
+    lib.ipx_group_push_member.argtypes = [vp, C.c_uint32, C.POINTER(Batch)]
     lib.ipx_group_finalize.argtypes = [vp, C.POINTER(Table)]
     lib.ipx_group_clear.argtypes = [vp]
     lib.ipx_group_last_error.argtypes = [vp, C.POINTER(Error)]

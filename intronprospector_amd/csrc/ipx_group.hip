@@ -263,6 +263,19 @@ int ipx_group_push_batch(ipx_group *g, const ipx_batch *b) {
     return IPX_OK;
 }
 
+// One member's share, sharded by the caller: the batch may lie in that member's DEVICE memory (an input that is
+// already resident, as in bench.py's steps) or in host memory.  base_read_index places it in the run's input order.
+int ipx_group_push_member(ipx_group *g, uint32_t member, const ipx_batch *b) {
+    if (!g || !b) return IPX_EINVAL;
+    if (member >= g->m.size()) return gfail(g, IPX_EINVAL, "ipx_group_push_member: no such member");
+    if (b->n_alignments == 0) return IPX_OK;
+    Member &mb = g->m[member];
+    const int r = ipx_push_batch(mb.h, b);
+    if (r) return mfail(g, mb, r);
+    mb.n_alignments += b->n_alignments;
+    return IPX_OK;
+}
+
 int ipx_group_clear(ipx_group *g) {
     if (!g) return IPX_EINVAL;
     for (Member &mb : g->m) {

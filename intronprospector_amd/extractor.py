@@ -299,6 +299,11 @@ class JunctionsExtractorGroup:
         self._check(self.lib.ipx_group_push_batch(self.g, C.byref(b)))
         self.next_read_index = base_read_index + n
 
+    def push_member_device(self, member, n, n_words, ptrs, base_read_index):
+        """one member's share from that member's device memory (ptrs: tid,pos,flag,xs,nh,cigar_off,n_cigar,cigar)"""
+        b = L.Batch(n, n_words, base_read_index, *ptrs, L.IPX_MEM_DEVICE)
+        self._check(self.lib.ipx_group_push_member(self.g, member, C.byref(b)))
+
     def get_junctions(self):
         t = L.Table()
         rc = self.lib.ipx_group_finalize(self.g, C.byref(t))

@@ -59,6 +59,32 @@ def test_group_of_members_sharing_the_gpu_equals_oracle(members, genome, oracle_
     grp.close()
 
 
+def test_group_members_fed_from_device_memory(oracle_lib):
+    """ipx_group_push_member: the caller shards, every member takes its share from (its own) device memory -- how a
+    step of the group is timed on resident input"""
+    import torch
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(90_000, seed=63, n_targets=4, target_len=2_800_000, n_sites=900)
+    keys = ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")
+    grp = ipa.JunctionsExtractorGroup([0, 0, 0], targets=names)
+    n = len(batch["tid"])
+    cuts = [0, n // 4, n // 2, n]
+    keep = []
+    for m in range(3):
+        part = synth.slice_batch(batch, cuts[m], cuts[m + 1])
+        arrs = [torch.from_numpy(part[k]).to("cuda:0") for k in keys]
+        keep.append(arrs)
+        grp.push_member_device(m, len(part["tid"]), len(part["cigar"]), [a.data_ptr() for a in arrs], cuts[m])
+    torch.cuda.synchronize()
+    dev = grp.get_junctions()
+    ref, err = _oracle(batch, names)
+    assert err is None and "error" not in dev
+    helpers.compare_tables(dev, ref)
+    assert dev["n_alignments"] == n
+    grp.close()
+
+
 def test_group_raises_the_earliest_error(oracle_lib):
     """junctions_extractor.cc:73-74,312-313: a 'P' operation in the second member's range, a spliced FUNMAP read
     in the first one's: the group reports what the reference's loop would have thrown first"""

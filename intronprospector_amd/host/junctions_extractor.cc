@@ -487,8 +487,7 @@ void JunctionsExtractor::identify_junctions_for_target(int target_index) {
         process_alignment(aln_buf_);
         if (pass_through_) {                    // process_target_alignment, :647-650
             if (set_xs_ || set_ts_) {
-                pt_pending_.push_back(aln_buf_);
-                pt_read_index_.push_back(next_read_index_ + batch_[cur_].n - 1);
+                pt_pending_.add(aln_buf_, next_read_index_ + batch_[cur_].n - 1);
             } else {
                 pass_through_->write(aln_buf_, 0, false, false);
             }
@@ -641,11 +640,69 @@ static uint64_t counting_row(const ipx_table &t, const ipx_record &r) {
 
 // record_junction's orientCnt (junctions_extractor.cc:526-528) per waiting alignment, then
 // update_strand_tag + write_pass_through (:540-547,647-650)
+void JunctionsExtractor::PendingSpool::add(const AlnRecord &rec, uint64_t read_index) {
+    if (n == 0) {
+        first_read_index = read_index;
+        const char *e = getenv("IPX_PASS_THROUGH_BUFFER_MB");
+        if (e && atol(e) >= 0) cap_bytes = (size_t)atol(e) << 20;
+    }
+    const uint32_t hdr[2] = {(uint32_t)rec.raw.size(), rec.aux_off};
+    buf.append(reinterpret_cast<const char *>(hdr), sizeof hdr);
+    buf.append(rec.raw);
+    ++n;
+    if (buf.size() > cap_bytes) {                   // the memory share is full: the rest waits on disk
+        if (!spill && !(spill = std::tmpfile())) throw std::runtime_error("cannot create a temporary file for the waiting pass-through alignments");
+        if (fwrite(buf.data(), 1, buf.size(), spill) != buf.size()) throw std::runtime_error("Error writing the waiting pass-through alignments to their temporary file");
+        spilled_bytes += buf.size();
+        buf.clear();
+    }
+}
+
+template <typename F> void JunctionsExtractor::PendingSpool::drain(F fn) {
+    uint64_t k = 0;
+    std::string raw;
+    auto walk = [&](const char *p, size_t len) -> size_t {      // whole records of [p, p + len): bytes consumed
+        size_t off = 0;
+        while (off + 8 <= len) {
+            uint32_t hdr[2];
+            memcpy(hdr, p + off, 8);
+            if (off + 8 + hdr[0] > len) break;
+            raw.assign(p + off + 8, hdr[0]);
+            fn(raw, hdr[1], k++);
+            off += 8 + (size_t)hdr[0];
+        }
+        return off;
+    };
+    if (spill) {
+        rewind(spill);
+        std::string chunk;
+        uint64_t left = spilled_bytes;
+        const size_t step = (size_t)64 << 20;
+        while (left) {
+            const size_t old = chunk.size(), want = (size_t)std::min<uint64_t>(left, step);
+            chunk.resize(old + want);
+            if (fread(&chunk[old], 1, want, spill) != want) throw std::runtime_error("Error reading the waiting pass-through alignments back");
+            left -= want;
+            const size_t used = walk(chunk.data(), chunk.size());
+            chunk.erase(0, used);
+        }
+        if (!chunk.empty()) throw std::runtime_error("Error reading the waiting pass-through alignments back");
+        fclose(spill);
+        spill = nullptr;
+        spilled_bytes = 0;
+    }
+    if (walk(buf.data(), buf.size()) != buf.size() || k != n) throw std::runtime_error("Error reading the waiting pass-through alignments back");
+    buf.clear();
+    buf.shrink_to_fit();
+    n = 0;
+}
+
 void JunctionsExtractor::write_pending_pass_through(const ipx_table &t, const std::vector<ipx_record> &recs) {
-    std::vector<int> orient(pt_pending_.size(), 0);
+    // update_strand_tag looks at the SIGN of orientCnt only (:540-547): one saturating byte per waiting alignment
+    std::vector<int8_t> orient(pt_pending_.n, 0);
     // read indices grow by one per processed alignment and every waiting alignment was processed,
     // so the waiting ones hold consecutive indices
-    const uint64_t first = pt_read_index_.front();
+    const uint64_t first = pt_pending_.first_read_index;
     for (const ipx_record &r : recs) {
         const uint64_t read = IPX_RECORD_READ(r.order);
         if (read < first || read - first >= orient.size()) continue;
@@ -653,12 +710,17 @@ void JunctionsExtractor::write_pending_pass_through(const ipx_table &t, const st
         if (row == t.n_junctions) continue;
         const Junction &j = table_[row];
         // Junction::is_canonical, junctions.hh:187-191: canonical sites are capitalized
-        if (!j.splice_sites.empty() && j.splice_sites[0] >= 'A' && j.splice_sites[0] <= 'Z')
-            orient[read - first] += (j.strand == '+') ? 1 : -1;
+        if (!j.splice_sites.empty() && j.splice_sites[0] >= 'A' && j.splice_sites[0] <= 'Z') {
+            int8_t &o = orient[read - first];
+            if (j.strand == '+') { if (o < 127) ++o; } else { if (o > -127) --o; }
+        }
     }
-    for (size_t i = 0; i < pt_pending_.size(); ++i) pass_through_->write(pt_pending_[i], orient[i], set_xs_, set_ts_);
-    pt_pending_.clear();
-    pt_read_index_.clear();
+    AlnRecord rec;
+    pt_pending_.drain([&](const std::string &raw, uint32_t aux_off, uint64_t k) {
+        rec.raw = raw;
+        rec.aux_off = aux_off;
+        pass_through_->write(rec, orient[k], set_xs_, set_ts_);
+    });
 }
 
 void JunctionsExtractor::write_trace(const ipx_table &t, const std::vector<ipx_record> &recs) {

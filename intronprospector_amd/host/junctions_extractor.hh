@@ -17,6 +17,7 @@
 #define IPX_HOST_JUNCTIONS_EXTRACTOR_HH
 #include <cstdint>
 #include <iostream>
+#include <cstdio>
 #include <memory>
 #include <set>
 #include <string>
@@ -148,8 +149,21 @@ private:
     // strand tag is to be set (the count needs the target's table); otherwise they are written at once
     bool set_xs_, set_ts_;
     std::unique_ptr<PassThroughWriter> pass_through_;
-    std::vector<AlnRecord> pt_pending_;
-    std::vector<uint64_t> pt_read_index_;
+    // Alignments that wait for their target's table before they can be written with a strand tag.  The reference
+    // streams (junctions_extractor.cc:647-650); here a read's orientation count comes from the finished table, so the
+    // raw records wait -- in memory up to IPX_PASS_THROUGH_BUFFER_MB (default 256), beyond that in an unlinked
+    // temporary file, read back once, in order.  What stays in memory per waiting alignment is one byte.
+    struct PendingSpool {
+        std::string buf;                    // [u32 length][u32 aux_off][raw bytes] ...
+        FILE *spill = nullptr;
+        uint64_t n = 0, spilled_bytes = 0, first_read_index = 0;
+        size_t cap_bytes = (size_t)256 << 20;
+        bool empty() const { return n == 0; }
+        void add(const AlnRecord &rec, uint64_t read_index);
+        // fn(raw, aux_off, k) for the k-th waiting alignment, in input order; empties the spool
+        template <typename F> void drain(F fn);
+        ~PendingSpool() { if (spill) fclose(spill); }
+    } pt_pending_;
     void write_pending_pass_through(const ipx_table &t, const std::vector<ipx_record> &recs);
     std::vector<ipx_record> export_records();
 

@@ -98,6 +98,13 @@ def test_cli_pass_through_and_strand_tags(cli, golden, tmp_path):
     subprocess.run([cli, fa, "--set-XS-strand-tag", "--pass-through=" + sam_out, star], check=True)
     exp = subprocess.run([hc, "dump-aln", sam_out], stdout=subprocess.PIPE, check=True).stdout
     assert got == exp and b"\t43\t" in got
+    # the waiting alignments spilled to their temporary file (IPX_PASS_THROUGH_BUFFER_MB=0: every record goes to disk
+    # and is read back in order): the same bytes
+    env = dict(os.environ, IPX_PASS_THROUGH_BUFFER_MB="0")
+    subprocess.run([cli, fa, "--set-XS-strand-tag", "--set-TS-strand-tag", "--pass-through=" + out, star], check=True, env=env)
+    assert open(out, "rb").read() == open(os.path.join(gexp, "testStrandTagAdd.sam"), "rb").read()
+    subprocess.run([cli, fa, "--set-XS-strand-tag", "--pass-through=" + bam_out, bam], check=True, env=env)
+    assert subprocess.run([hc, "dump-aln", bam_out], stdout=subprocess.PIPE, check=True).stdout == exp
     # the reference's --unsorted loop never writes the alignments (identify_junctions_for_bam,
     # junctions_extractor.cc:678-683): header only
     subprocess.run([cli, "--unsorted", fa, "--pass-through=" + out, star], check=True)

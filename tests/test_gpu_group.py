@@ -8,6 +8,7 @@ import tempfile
 
 import numpy as np
 import pytest
+import torch            # noqa: F401  (before libipx.so: the HIP runtime torch brings along must be the one the process keeps)
 
 from tests import helpers
 from tests.oracle_binding import Oracle, OracleError
@@ -62,7 +63,6 @@ def test_group_of_members_sharing_the_gpu_equals_oracle(members, genome, oracle_
 def test_group_members_fed_from_device_memory(oracle_lib):
     """ipx_group_push_member: the caller shards, every member takes its share from (its own) device memory -- how a
     step of the group is timed on resident input"""
-    import torch
     import intronprospector_amd as ipa
     from intronprospector_amd import synth
     batch, names, _ = synth.short_reads(90_000, seed=63, n_targets=4, target_len=2_800_000, n_sites=900)

@@ -255,7 +255,7 @@ typedef struct ipx_bam_batch {
 int ipx_push_bam(ipx_handle *h, const ipx_bam_batch *batch);
 int ipx_push_bam_async(ipx_handle *h, const ipx_bam_batch *batch);
 
-/* EXPERIMENT (not used by the command line yet): BGZF blocks inflated on the device, one lane per block --
+/* The inflater of ipx_decode_bgzf on its own (tests, timing): BGZF blocks inflated on the device, one lane per block --
  * what htslib's bgzf.c does block by block under sam_read1 (junctions_extractor.cc:620-634).  comp[0, n_bytes):
  * the file's bytes (host memory); block b's raw DEFLATE stream is comp[in_off[b], in_off[b + 1]) (in_off has
  * n_blocks + 1 entries; the BGZF header and the CRC / ISIZE trailer lie outside), its ISIZE is isize[b] (<= 65536)
@@ -265,6 +265,33 @@ int ipx_push_bam_async(ipx_handle *h, const ipx_bam_batch *batch);
 int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_bytes, const uint64_t *in_off,
                      const uint32_t *isize, const uint64_t *out_off, uint64_t n_blocks, uint8_t *out,
                      uint64_t out_bytes, uint32_t *status, float *kernel_ms);
+
+/* A whole BGZF-compressed BAM file decoded on the device (ABI 3) -- what sam_read1 + bgzf.c do record by record and
+ * block by block in front of process_alignment (junctions_extractor.cc:620-634): the caller reads the FILE's bytes,
+ * walks the block headers (payload_begin / payload_end: block b's raw DEFLATE stream; isize / crc32: its trailer) and
+ * says where the alignment records begin in the inflated stream (records_begin: the header's length).  The device
+ * inflates every block (one lane per block), checks every CRC-32, finds the records -- every block must begin at a
+ * record boundary, which htslib's writers see to (bgzf_flush_try before every record); a file that lets records
+ * straddle block ends is refused, the caller then reads it the serial way -- and decodes them as ipx_push_bam does,
+ * into ONE device-resident SoA batch of all alignments: *out (memory = IPX_MEM_DEVICE, base_read_index = 0), owned by
+ * the handle and valid until the next ipx_decode_bgzf / ipx_destroy.  Slices of it (pointers advanced, cigar and
+ * n_cigar_words kept: cigar_off stays absolute) go to ipx_push_batch target by target.
+ * Returns IPX_EINVAL with the reason in ipx_last_error().detail when anything about the file does not check out
+ * (a block that does not inflate to its ISIZE, a CRC mismatch, an unaligned block, a record that does not parse):
+ * nothing was pushed; the caller's own reader then reports the damage in its words. */
+typedef struct ipx_bgzf_file {
+    const uint8_t  *bytes;          /* the file, host memory */
+    uint64_t n_bytes;
+    uint64_t n_blocks;
+    const uint64_t *payload_begin;  /* n_blocks offsets into bytes */
+    const uint64_t *payload_end;
+    const uint32_t *isize;
+    const uint32_t *crc32;
+    uint64_t records_begin;
+    const int32_t  *tid_map;        /* refID -> tid, or NULL */
+    uint32_t n_tid_map;
+} ipx_bgzf_file;
+int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *file, ipx_batch *out);
 /* pinned (page-locked) host memory, hipHostMalloc / hipHostFree */
 int ipx_host_alloc(void **out, size_t bytes);
 int ipx_host_free(void *p);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "ipx_group_last_error", "ipx_group_uses_rccl",
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
     "ipx_push_bam", "ipx_push_bam_async", "ipx_bgzf_inflate",
-    "ipx_records_partition_slots", "ipx_records_adopt_slots", "ipx_use_stream", "ipx_copy_async",
+    "ipx_records_partition_slots", "ipx_records_adopt_slots", "ipx_use_stream", "ipx_copy_async", "ipx_decode_bgzf",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -79,6 +79,12 @@ class Error(C.Structure):
         ("start", C.c_uint32), ("end", C.c_uint32), ("retlen", C.c_int32), ("op", C.c_char),
         ("detail", C.c_char * 235), ("order", C.c_uint64),
     ]
+
+
+class BgzfFile(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("n_bytes", C.c_uint64), ("n_blocks", C.c_uint64), ("payload_begin", C.c_void_p),
+                ("payload_end", C.c_void_p), ("isize", C.c_void_p), ("crc32", C.c_void_p), ("records_begin", C.c_uint64),
+                ("tid_map", C.c_void_p), ("n_tid_map", C.c_uint32)]
 
 
 class SlotsInfo(C.Structure):
@@ -133,6 +139,7 @@ def load():
     lib.ipx_records_partition_slots.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int32, vp]
     lib.ipx_records_adopt_slots.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64, C.POINTER(SlotsInfo)]
     lib.ipx_use_stream.argtypes = [vp, vp]
+    lib.ipx_decode_bgzf.argtypes = [vp, C.POINTER(BgzfFile), C.POINTER(Batch)]
     lib.ipx_copy_async.argtypes = [vp, vp, vp, C.c_uint64]
     lib.ipx_records_export.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -148,6 +148,7 @@ struct ipx_handle {
     // (the lowest 8 varying key bits), so that pass saves a whole pass over bits 0..7 that hardly vary.
     DigitSpec first_window{0, 8, 0, 0}, first_hint{0, 8, 0, 0};
     DevBuf counters, stage, sort_ws, scratch, out_arena, rank_bitmap, d_small, out_arena2, d_xchg, close_ws, defer, bam_raw, bs_ws;
+    DevBuf bz_comp, bz_out, bz_tab, bz_soa, bz_cigar, bz_ws;      // ipx_decode_bgzf: file bytes, inflated stream, tables, the decoded batch
     // pinned host
     void *pin_small = nullptr;     // 4 KiB of read-back scalars
     uint32_t *mail_host = nullptr, *mail_dev = nullptr;      // k_publish's mailbox (pinned, host-coherent)
@@ -197,6 +198,20 @@ static hipError_t ipx_stream_wait(hipStream_t s) {
     while ((e = hipStreamQuery(s)) == hipErrorNotReady) {
     }
     return e;
+}
+
+// smallest index of a block whose status is not 0, + 1, into *first (0: none); *first starts at 0
+__global__ void k_first_bad_block(const uint32_t *__restrict__ status, uint32_t n, uint32_t *first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && status[i]) {
+        // (0 means none: take the minimum over i + 1 with 0 standing for "unset")
+        uint32_t old = *first;
+        while (old == 0 || old > i + 1) {
+            const uint32_t prev = atomicCAS(first, old, i + 1);
+            if (prev == old) break;
+            old = prev;
+        }
+    }
 }
 
 // the handle's counters, set in stream order (ipx_clear, re-scans)
@@ -489,7 +504,8 @@ int ipx_destroy(ipx_handle *h) {
     for (DevBuf *b : {&h->d_rank_of_tid, &h->d_tid_of_rank, &h->d_twobit, &h->d_mask, &h->d_seq_len,
                       &h->d_seq_word2, &h->d_seq_wordm, &h->d_seq_of_rank, &h->d_rank_seq, &h->items_a, &h->items_b, &h->pays, &h->cnts, &h->dig_a, &h->dig_b,
                       &h->counters, &h->stage, &h->sort_ws, &h->scratch, &h->out_arena,
-                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer, &h->bam_raw, &h->bs_ws})
+                      &h->rank_bitmap, &h->d_small, &h->out_arena2, &h->d_xchg, &h->close_ws, &h->defer, &h->bam_raw, &h->bs_ws,
+                      &h->bz_comp, &h->bz_out, &h->bz_tab, &h->bz_soa, &h->bz_cigar, &h->bz_ws})
         release(*b);
     if (h->pin_small) (void)hipHostFree(h->pin_small);
     if (h->mail_host) (void)hipHostFree(h->mail_host);
@@ -1546,6 +1562,105 @@ int ipx_records_adopt_slots(ipx_handle *h, uint32_t n_slots, uint64_t slot_recor
     h->n_records = info->n_records;
     h->n_raw = info->n_records + merged;
     h->n_alignments = n_alignments;
+    return IPX_OK;
+}
+
+int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
+    if (!h || !f || !out) return IPX_EINVAL;
+    memset(out, 0, sizeof *out);
+    if (!f->bytes || !f->n_blocks || !f->payload_begin || !f->payload_end || !f->isize || !f->crc32 || (f->n_tid_map && !f->tid_map))
+        return fail(h, IPX_EINVAL, "ipx_decode_bgzf: null array%s%ld", "", 0);
+    (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
+    const uint64_t nb = f->n_blocks;
+    if (nb >= (1ull << 31)) return fail(h, IPX_EINVAL, "ipx_decode_bgzf: too many blocks%s%ld", "", 0);
+    std::vector<uint64_t> out_off(nb + 1);
+    uint64_t T = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        if (f->payload_begin[b] > f->payload_end[b] || f->payload_end[b] > f->n_bytes || f->isize[b] > 65536 ||
+            (b && f->payload_begin[b] < f->payload_end[b - 1]))
+            return fail(h, IPX_EINVAL, "ipx_decode_bgzf: block table out of order or out of the file (block %s%ld)", "", (long)b);
+        out_off[b] = T;
+        T += f->isize[b];
+    }
+    out_off[nb] = T;
+    if (f->records_begin > T) return fail(h, IPX_EINVAL, "ipx_decode_bgzf: records_begin beyond the inflated stream%s%ld", "", 0);
+    auto al = [](uint64_t x) { return (x + 255) & ~255ull; };
+    int rc;
+    // tables: payload_begin, payload_end, out_off (u64), isize, crc, status, count, prefix (u32), span_begin, span_first (u64), flags
+    const uint64_t t_pb = 0, t_pe = al(t_pb + 8 * nb), t_oo = al(t_pe + 8 * nb), t_is = al(t_oo + 8 * (nb + 1)), t_crc = al(t_is + 4 * nb),
+                   t_st = al(t_crc + 4 * nb), t_cnt = al(t_st + 4 * nb), t_pre = al(t_cnt + 4 * (nb + 1)), t_sb = al(t_pre + 4 * (nb + 1)),
+                   t_sf = al(t_sb + 8 * (nb + 1)), t_sums = al(t_sf + 8 * (nb + 1)), t_flags = al(t_sums + 4 * (ipx_div_up(nb, 4096) + 8)),
+                   t_map = al(t_flags + 64), t_total = al(t_map + 4ull * f->n_tid_map);
+    if ((rc = ensure(h, h->bz_comp, f->n_bytes + 16))) return rc;
+    if ((rc = ensure(h, h->bz_out, T + 64))) return rc;
+    if ((rc = ensure(h, h->bz_tab, t_total + 256))) return rc;
+    if ((rc = ensure(h, h->bz_ws, ipx_bgzf_tables_bytes(nb)))) return rc;
+    char *tb = h->bz_tab.as<char>();
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->bz_comp.p, f->bytes, f->n_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->bz_comp.as<char>() + f->n_bytes, 0, 16, s));
+    HIPCHK(hipMemsetAsync(h->bz_out.as<char>() + T, 0, 64, s));
+    HIPCHK(hipMemcpyAsync(tb + t_pb, f->payload_begin, 8 * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tb + t_pe, f->payload_end, 8 * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tb + t_oo, out_off.data(), 8 * (nb + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tb + t_is, f->isize, 4 * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tb + t_crc, f->crc32, 4 * nb, hipMemcpyHostToDevice, s));
+    if (f->n_tid_map) HIPCHK(hipMemcpyAsync(tb + t_map, f->tid_map, 4ull * f->n_tid_map, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(tb + t_flags, 0, 64, s));
+    uint32_t *status = (uint32_t *)(tb + t_st), *flags = (uint32_t *)(tb + t_flags);
+    HIPCHK(ipx_launch_bgzf_inflate(s, h->bz_comp.as<uint8_t>(), (const uint64_t *)(tb + t_pb), (const uint64_t *)(tb + t_pe),
+                                   (const uint32_t *)(tb + t_is), (const uint64_t *)(tb + t_oo), (const uint32_t *)(tb + t_crc), nb,
+                                   h->bz_out.as<uint8_t>(), h->bz_ws.as<uint32_t>(), status));
+    // flags[0] = unaligned, flags[1] = first bad block + 1 (inflate status or CRC), flags[2] = records in all
+    HIPCHK(ipx_launch_bam_count_blocks(s, h->bz_out.as<uint8_t>(), (const uint64_t *)(tb + t_oo), (const uint32_t *)(tb + t_is), nb,
+                                       f->records_begin, (uint32_t *)(tb + t_cnt), (uint32_t *)(tb + t_pre), (uint32_t *)(tb + t_sums),
+                                       flags + 2, (uint64_t *)(tb + t_sb), (uint64_t *)(tb + t_sf), flags));
+    hipLaunchKernelGGL(k_first_bad_block, dim3((uint32_t)ipx_div_up(nb, 256)), dim3(256), 0, s, status, (uint32_t)nb, flags + 1);
+    HIPCHK(hipGetLastError());
+    if ((rc = read_back(h, h->pin_small, flags, 4))) return rc;
+    const uint32_t *fl = (const uint32_t *)h->pin_small;
+    if (fl[1]) {
+        uint32_t st = 0;
+        HIPCHK(hipMemcpyAsync(&st, status + (fl[1] - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ipx_stream_wait(s));
+        return fail(h, IPX_EINVAL, (st & 0x100u) ? "ipx_decode_bgzf: CRC-32 mismatch%s in block %ld" : "ipx_decode_bgzf: a block does not inflate to its ISIZE%s (block %ld)",
+                    "", (long)fl[1] - 1);
+    }
+    if (fl[0]) return fail(h, IPX_EINVAL, "ipx_decode_bgzf: records straddle block ends%s%ld", "", 0);
+    const uint64_t n = fl[2];
+    // the batch: seven arrays of n entries, then the CIGAR words
+    const uint64_t o_tid = 0, o_pos = al(o_tid + n * 4), o_flag = al(o_pos + n * 4), o_xs = al(o_flag + n * 2), o_nh = al(o_xs + n),
+                   o_off = al(o_nh + n), o_nc = al(o_off + n * 4), soa_total = al(o_nc + n * 4);
+    if ((rc = ensure(h, h->bz_soa, soa_total + 256))) return rc;
+    if ((rc = ensure(h, h->bam_raw, ipx_bam_workspace_bytes(n) + 256))) return rc;
+    char *sa = h->bz_soa.as<char>();
+    uint32_t *bam_err = flags + 3, *total_dev = nullptr;
+    if (n) {
+        HIPCHK(ipx_launch_bam_decode_fields(s, h->bz_out.as<uint8_t>(), (const uint64_t *)(tb + t_sb), (const uint64_t *)(tb + t_sf),
+                                            (uint32_t)nb, n, f->n_tid_map ? (const int32_t *)(tb + t_map) : nullptr, f->n_tid_map,
+                                            (int32_t *)(sa + o_tid), (int32_t *)(sa + o_pos), (uint16_t *)(sa + o_flag), (uint8_t *)(sa + o_xs),
+                                            (uint8_t *)(sa + o_nh), (uint32_t *)(sa + o_off), (uint32_t *)(sa + o_nc), h->bam_raw.p, bam_err,
+                                            &total_dev));
+        if ((rc = read_back(h, h->pin_small, bam_err, 1, total_dev, 1))) return rc;
+        const uint32_t *r2 = (const uint32_t *)h->pin_small;
+        if (r2[0] != 0xffffffffu)
+            return fail(h, IPX_EINVAL, "ipx_decode_bgzf: malformed BAM record%s (alignment %ld)", "", (long)r2[0] - 1);
+        const uint64_t nw = r2[1];
+        if ((rc = ensure(h, h->bz_cigar, (nw + 4) * 4 + 256))) return rc;
+        HIPCHK(ipx_launch_bam_decode_cigar(s, h->bz_out.as<uint8_t>(), n, nw, (const uint32_t *)(sa + o_off), (const uint32_t *)(sa + o_nc),
+                                           h->bz_cigar.as<uint32_t>(), h->bam_raw.p, bam_err));
+        if ((rc = read_back(h, h->pin_small, bam_err, 1))) return rc;
+        if (((const uint32_t *)h->pin_small)[0] != 0xffffffffu)
+            return fail(h, IPX_EINVAL, "ipx_decode_bgzf: CIGAR lengths and records disagree%s%ld", "", 0);
+        out->n_cigar_words = nw;
+    }
+    out->n_alignments = n;
+    out->base_read_index = 0;
+    out->tid = (const int32_t *)(sa + o_tid); out->pos = (const int32_t *)(sa + o_pos); out->flag = (const uint16_t *)(sa + o_flag);
+    out->xs = (const uint8_t *)(sa + o_xs); out->nh = (const uint8_t *)(sa + o_nh); out->cigar_off = (const uint32_t *)(sa + o_off);
+    out->n_cigar = (const uint32_t *)(sa + o_nc); out->cigar = h->bz_cigar.as<uint32_t>();
+    out->memory = IPX_MEM_DEVICE;
     return IPX_OK;
 }
 

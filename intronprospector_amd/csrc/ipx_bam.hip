@@ -186,10 +186,11 @@ size_t ipx_bam_workspace_bytes(uint64_t n) {
     return (size_t)(16 * n + 4 * (ipx_div_up(n, 4096) + 1) + 256 + 64);
 }
 
-hipError_t ipx_launch_bam_decode(hipStream_t s, const uint8_t *bytes, const uint64_t *span_begin, const uint64_t *span_first,
-                                 uint32_t n_spans, uint64_t n, uint64_t n_words, const int32_t *tid_map, uint32_t n_tid_map,
-                                 int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *xs, uint8_t *nh, uint32_t *cigar_off,
-                                 uint32_t *n_cigar, uint32_t *cigar, void *workspace, uint32_t *err) {
+// stage 1: record starts, fixed fields, tags, CIGAR lengths and their prefix (cigar_off); *total (device) = CIGAR words
+hipError_t ipx_launch_bam_decode_fields(hipStream_t s, const uint8_t *bytes, const uint64_t *span_begin, const uint64_t *span_first,
+                                        uint32_t n_spans, uint64_t n, const int32_t *tid_map, uint32_t n_tid_map,
+                                        int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *xs, uint8_t *nh, uint32_t *cigar_off,
+                                        uint32_t *n_cigar, void *workspace, uint32_t *err, uint32_t **total_out) {
     char *ws = static_cast<char *>(workspace);
     uint64_t *rec_off = reinterpret_cast<uint64_t *>(ws);
     uint64_t *cig_src = rec_off + n;
@@ -202,7 +203,29 @@ hipError_t ipx_launch_bam_decode(hipStream_t s, const uint8_t *bytes, const uint
                        tid, pos, flag, xs, nh, n_cigar, cig_src, err);
     hipError_t e = ipx_launch_scan_u32(s, n_cigar, cigar_off, n, sums, total);
     if (e != hipSuccess) return e;
+    if (total_out) *total_out = total;
+    return hipGetLastError();
+}
+
+// stage 2: the CIGAR words; n_words = what *total must say (the caller's count, or what it read back from stage 1)
+hipError_t ipx_launch_bam_decode_cigar(hipStream_t s, const uint8_t *bytes, uint64_t n, uint64_t n_words, const uint32_t *cigar_off,
+                                       const uint32_t *n_cigar, uint32_t *cigar, void *workspace, uint32_t *err) {
+    char *ws = static_cast<char *>(workspace);
+    uint64_t *rec_off = reinterpret_cast<uint64_t *>(ws);
+    uint64_t *cig_src = rec_off + n;
+    uint32_t *sums = reinterpret_cast<uint32_t *>(cig_src + n);
+    uint32_t *total = sums + ipx_div_up(n, 4096) + 1 + 32;
     hipLaunchKernelGGL(k_bam_cigar, dim3((uint32_t)ipx_div_up(n, 256)), dim3(256), 0, s, bytes, cig_src, n_cigar, cigar_off, n,
                        total, n_words, cigar, err);
     return hipGetLastError();
+}
+
+hipError_t ipx_launch_bam_decode(hipStream_t s, const uint8_t *bytes, const uint64_t *span_begin, const uint64_t *span_first,
+                                 uint32_t n_spans, uint64_t n, uint64_t n_words, const int32_t *tid_map, uint32_t n_tid_map,
+                                 int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *xs, uint8_t *nh, uint32_t *cigar_off,
+                                 uint32_t *n_cigar, uint32_t *cigar, void *workspace, uint32_t *err) {
+    hipError_t e = ipx_launch_bam_decode_fields(s, bytes, span_begin, span_first, n_spans, n, tid_map, n_tid_map, tid, pos, flag, xs,
+                                                nh, cigar_off, n_cigar, workspace, err, nullptr);
+    if (e != hipSuccess) return e;
+    return ipx_launch_bam_decode_cigar(s, bytes, n, n_words, cigar_off, n_cigar, cigar, workspace, err);
 }

@@ -349,6 +349,23 @@ hipError_t ipx_launch_bam_decode(hipStream_t s, const uint8_t *bytes, const uint
                                  int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *xs, uint8_t *nh, uint32_t *cigar_off,
                                  uint32_t *n_cigar, uint32_t *cigar, void *workspace, uint32_t *err);
 
+// the same in two stages, for a caller that learns the number of CIGAR words from the records themselves (ipx_decode_bgzf)
+hipError_t ipx_launch_bam_decode_fields(hipStream_t s, const uint8_t *bytes, const uint64_t *span_begin, const uint64_t *span_first,
+                                        uint32_t n_spans, uint64_t n, const int32_t *tid_map, uint32_t n_tid_map,
+                                        int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *xs, uint8_t *nh, uint32_t *cigar_off,
+                                        uint32_t *n_cigar, void *workspace, uint32_t *err, uint32_t **total_out);
+hipError_t ipx_launch_bam_decode_cigar(hipStream_t s, const uint8_t *bytes, uint64_t n, uint64_t n_words, const uint32_t *cigar_off,
+                                       const uint32_t *n_cigar, uint32_t *cigar, void *workspace, uint32_t *err);
+
+// ipx_inflate.hip: BGZF blocks inflated (and CRC-checked) on the device, records counted per block
+size_t ipx_bgzf_tables_bytes(uint64_t n_blocks);
+hipError_t ipx_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end,
+                                   const uint32_t *isize, const uint64_t *out_off, const uint32_t *crc, uint64_t n_blocks,
+                                   uint8_t *out, uint32_t *tables, uint32_t *status);
+hipError_t ipx_launch_bam_count_blocks(hipStream_t s, const uint8_t *bytes, const uint64_t *out_off, const uint32_t *isize,
+                                       uint64_t n_blocks, uint64_t records_begin, uint32_t *count, uint32_t *prefix, uint32_t *sums,
+                                       uint32_t *total, uint64_t *span_begin, uint64_t *span_first, uint32_t *unaligned);
+
 // ipx_exchange.hip: key-range partitioning of the pending records for the multi-GPU exchange
 hipError_t ipx_launch_sample(hipStream_t s, const uint4 *items, uint64_t n, const KeyLayout &kl,
                              uint32_t n_samples, unsigned long long *out /* device */);

@@ -130,7 +130,9 @@ __device__ __forceinline__ uint32_t decode(Bits &b, const uint16_t *tab, uint32_
     return 0xffffffffu;
 }
 
+// in_end == nullptr: block b's payload ends where block b + 1's begins (in_off has n_blocks + 1 entries)
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
+                                                     const uint64_t *__restrict__ in_end,
                                                      const uint32_t *__restrict__ isize, const uint64_t *__restrict__ out_off,
                                                      uint64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tables,
                                                      uint32_t *__restrict__ status) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     uint16_t *sll = reinterpret_cast<uint16_t *>(slice + O_SLL), *sd = reinterpret_cast<uint16_t *>(slice + O_SD);
     uint8_t *lens = slice + O_LENS;
     uint16_t *cll = reinterpret_cast<uint16_t *>(slice + O_CNT), *cd = cll + 16;
-    Bits b{comp, in_off[blk], in_off[blk + 1], 0, 0, 0};
+    Bits b{comp, in_off[blk], in_end ? in_end[blk] : in_off[blk + 1], 0, 0, 0};
     uint8_t *const o = out + out_off[blk];
     const uint32_t cap = isize[blk];
     uint32_t n_out = 0, err = 0;
@@ -250,7 +252,95 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     status[blk] = err;
 }
 
+// CRC-32 (the gzip polynomial, reflected) of every inflated block against the value in its trailer: one lane per block,
+// four bytes per step through slicing tables in LDS.  A block whose sum differs gets 0x100 OR-ed into its status.
+__global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+                                                 const uint32_t *__restrict__ isize, const uint32_t *__restrict__ crc_expected,
+                                                 uint64_t n_blocks, uint32_t *__restrict__ status) {
+    __shared__ uint32_t T[4][256];
+    for (uint32_t i = threadIdx.x; i < 256; i += 64) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+        T[0][i] = c;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += 64) {
+        uint32_t c = T[0][i];
+        for (uint32_t t = 1; t < 4; ++t) { c = T[0][c & 0xffu] ^ (c >> 8); T[t][i] = c; }
+    }
+    __syncthreads();
+    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blk >= n_blocks) return;
+    const uint8_t *p = out + out_off[blk];
+    const uint32_t n = isize[blk];
+    uint32_t c = 0xffffffffu, i = 0;
+    for (; i < n && ((uintptr_t)(p + i) & 3u); ++i) c = T[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    for (; i + 4 <= n; i += 4) {
+        c ^= *reinterpret_cast<const uint32_t *>(p + i);
+        c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
+    }
+    for (; i < n; ++i) c = T[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    if ((c ^ 0xffffffffu) != crc_expected[blk]) status[blk] |= 0x100u;
+}
+
+// Records of the BAM stream per block, on the premise that every block begins at a record boundary (htslib's writers
+// flush the block before a record that does not fit it): the chain of block_size words from the block's first byte --
+// from `records_begin` in the block that holds it: the header ends there -- must end exactly at the block's end.
+// count[b] = its records; a block whose chain does not fit sets *unaligned (the caller then reads the file the host's
+// way, which follows the chain serially).  Blocks before records_begin count nothing.
+__global__ __launch_bounds__(64) void k_bam_count_blocks(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ out_off,
+                                                         const uint32_t *__restrict__ isize, uint64_t n_blocks,
+                                                         uint64_t records_begin, uint32_t *__restrict__ count,
+                                                         uint64_t *__restrict__ span_begin, uint32_t *__restrict__ unaligned) {
+    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blk > n_blocks) return;
+    if (blk == n_blocks) { span_begin[blk] = out_off[blk - 1] + isize[blk - 1]; return; }
+    const uint64_t b0 = out_off[blk], end = b0 + isize[blk];
+    uint64_t off = b0 < records_begin ? records_begin : b0;
+    span_begin[blk] = off;              // the spans tile [records_begin, end of the stream): blocks of the header are empty spans
+    uint32_t k = 0;
+    while (off + 4 <= end) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(bytes + (off & ~3ull));
+        const uint32_t bs = __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)off & 3u);
+        if (bs < 32 || off + 4 + (uint64_t)bs > end) break;
+        ++k;
+        off += 4 + (uint64_t)bs;
+    }
+    if (off < end && end > records_begin) atomicOr(unaligned, 1u);       // the header's last block may end before records_begin
+    count[blk] = k;
+}
+
+// span_first[b] = records before block b (64-bit, as ipx_launch_bam_decode takes them) from the 32-bit prefix
+__global__ __launch_bounds__(256) void k_span_first(const uint32_t *__restrict__ prefix, const uint32_t *__restrict__ total,
+                                                    uint64_t n_blocks, uint64_t *__restrict__ span_first) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_blocks) span_first[i] = prefix[i];
+    else if (i == n_blocks) span_first[i] = *total;
+}
+
 }  // namespace
+
+size_t ipx_bgzf_tables_bytes(uint64_t n_blocks) { return (size_t)4 * LANE_WORDS * (n_blocks ? n_blocks : 1); }
+
+hipError_t ipx_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end,
+                                   const uint32_t *isize, const uint64_t *out_off, const uint32_t *crc, uint64_t n_blocks,
+                                   uint8_t *out, uint32_t *tables, uint32_t *status) {
+    const dim3 grid((uint32_t)ipx_div_up(n_blocks, 64));
+    hipLaunchKernelGGL(k_bgzf_inflate, grid, dim3(64), 0, s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status);
+    if (crc) hipLaunchKernelGGL(k_bgzf_crc, grid, dim3(64), 0, s, out, out_off, isize, crc, n_blocks, status);
+    return hipGetLastError();
+}
+
+hipError_t ipx_launch_bam_count_blocks(hipStream_t s, const uint8_t *bytes, const uint64_t *out_off, const uint32_t *isize,
+                                       uint64_t n_blocks, uint64_t records_begin, uint32_t *count, uint32_t *prefix, uint32_t *sums,
+                                       uint32_t *total, uint64_t *span_begin, uint64_t *span_first, uint32_t *unaligned) {
+    hipLaunchKernelGGL(k_bam_count_blocks, dim3((uint32_t)ipx_div_up(n_blocks + 1, 64)), dim3(64), 0, s, bytes, out_off, isize, n_blocks,
+                       records_begin, count, span_begin, unaligned);
+    hipError_t e = ipx_launch_scan_u32(s, count, prefix, n_blocks, sums, total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_span_first, dim3((uint32_t)ipx_div_up(n_blocks + 1, 256)), dim3(256), 0, s, prefix, total, n_blocks, span_first);
+    return hipGetLastError();
+}
 
 extern "C" int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_bytes, const uint64_t *in_off,
                                 const uint32_t *isize, const uint64_t *out_off, uint64_t n_blocks, uint8_t *out,
@@ -281,8 +371,8 @@ extern "C" int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_
     }
     if (rc == IPX_OK) {
         ok(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k_bgzf_inflate, dim3((uint32_t)ipx_div_up(n_blocks, 64)), dim3(64), 0, nullptr, d_comp, d_in_off, d_isize,
-                           d_out_off, n_blocks, d_out, d_tables, d_status);
+        hipLaunchKernelGGL(k_bgzf_inflate, dim3((uint32_t)ipx_div_up(n_blocks, 64)), dim3(64), 0, nullptr, d_comp, d_in_off,
+                           (const uint64_t *)nullptr, d_isize, d_out_off, n_blocks, d_out, d_tables, d_status);
         ok(hipGetLastError());
         ok(hipEventRecord(e1, nullptr));
         ok(hipEventSynchronize(e1));

@@ -2,6 +2,9 @@
 #include "junctions_extractor.hh"
 #include <chrono>
 #include <sys/stat.h>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 
@@ -240,6 +243,9 @@ void JunctionsExtractor::close() {
     reader_.reset();
     previous_target_ = -1;
     aln_pending_ = false;
+    device_file_ = device_file_tried_ = false;
+    dev_tid_.clear();
+    dev_cursor_ = 0;
 }
 
 // junctions_extractor.cc:620-634
@@ -345,9 +351,107 @@ void JunctionsExtractor::flush_batch() {
     if (rc != IPX_OK) throw_last_error(rc);
 }
 
+// The whole BGZF file to the device (ipx_decode_bgzf).  false: not this file (too small, not asked for, damaged,
+// unaligned, no memory): the caller goes on with the reader it has, which has not consumed a record yet.
+bool JunctionsExtractor::try_device_file() {
+    const char *e = getenv("IPX_DEVICE_INFLATE");
+    if (e && e[0] == '0') return false;
+    const std::string &path = reader_->path();
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28 || (!(e && e[0] == '1') && st.st_size < (16 << 20))) {
+        ::close(fd);
+        return false;
+    }
+    const size_t size = (size_t)st.st_size;
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) return false;
+    (void)madvise(map, size, MADV_SEQUENTIAL);
+    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, size};
+    const double t0 = timeline_ ? now_s() : 0.0;
+    // the block headers (SAM spec 4.1: gzip member with a BC extra subfield that holds BSIZE - 1)
+    const uint8_t *d = (const uint8_t *)map;
+    std::vector<uint64_t> pb, pe;
+    std::vector<uint32_t> isz, crc;
+    size_t p = 0;
+    while (p < size) {
+        if (p + 18 > size || d[p] != 31 || d[p + 1] != 139 || d[p + 2] != 8 || !(d[p + 3] & 4)) return false;
+        const size_t xlen = d[p + 10] | (d[p + 11] << 8);
+        if (p + 12 + xlen + 8 > size) return false;
+        size_t bsize = 0;
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const size_t slen = d[q + 2] | (d[q + 3] << 8);
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= p + 12 + xlen) bsize = (size_t)(d[q + 4] | (d[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || p + bsize > size) return false;
+        pb.push_back(p + 12 + xlen);
+        pe.push_back(p + bsize - 8);
+        uint32_t w[2];
+        memcpy(w, d + p + bsize - 8, 8);
+        crc.push_back(w[0]);
+        isz.push_back(w[1]);
+        p += bsize;
+    }
+    if (pb.empty()) return false;
+    ensure_device();
+    ipx_bgzf_file f{};
+    f.bytes = d;
+    f.n_bytes = size;
+    f.n_blocks = pb.size();
+    f.payload_begin = pb.data();
+    f.payload_end = pe.data();
+    f.isize = isz.data();
+    f.crc32 = crc.data();
+    f.records_begin = 4 + reader_->raw_header().size();          // magic, then what raw_header() holds: l_text ... the references
+    f.tid_map = canon_tid_.data();
+    f.n_tid_map = (uint32_t)canon_tid_.size();
+    if (ipx_decode_bgzf(h_, &f, &dev_batch_) != IPX_OK) return false;
+    dev_tid_.resize(dev_batch_.n_alignments);
+    if (!dev_tid_.empty() && ipx_copy(h_, dev_tid_.data(), dev_batch_.tid, dev_tid_.size() * sizeof(int32_t)) != IPX_OK) return false;
+    dev_cursor_ = 0;
+    if (timeline_) t_read_ += now_s() - t0;
+    return true;
+}
+
+// feed_target over the device-resident batch: the refIDs tell where the target's run of alignments ends
+bool JunctionsExtractor::feed_target_device(int32_t target_index, int32_t *other_tid) {
+    const uint64_t n = dev_batch_.n_alignments;
+    if (dev_cursor_ >= n) return false;
+    uint64_t j = n;
+    if (target_index != BamFeeder::ANY_TARGET) {
+        j = dev_cursor_;
+        if (dev_tid_[j] != target_index) { *other_tid = dev_tid_[j]; return true; }
+        while (j < n && dev_tid_[j] == target_index) ++j;
+    }
+    const uint64_t lo = dev_cursor_;
+    ipx_batch b = dev_batch_;                       // cigar, n_cigar_words stay: cigar_off is absolute
+    b.n_alignments = j - lo;
+    b.base_read_index = next_read_index_;
+    b.tid += lo; b.pos += lo; b.flag += lo; b.xs += lo; b.nh += lo; b.cigar_off += lo; b.n_cigar += lo;
+    const double t0 = timeline_ ? now_s() : 0.0;
+    const int rc = ipx_push_batch(h_, &b);
+    if (timeline_) { t_push_ += now_s() - t0; ++n_push_; }
+    next_read_index_ += j - lo;
+    dev_cursor_ = j;
+    table_valid_ = false;
+    if (rc != IPX_OK) throw_last_error(rc);
+    if (j < n) { *other_tid = dev_tid_[j]; return true; }
+    return false;
+}
+
 bool JunctionsExtractor::use_feeder() {
-    if (feeder_) return true;
+    if (feeder_ || device_file_) return true;
     if (!reader_ || !reader_->bgzf() || pass_through_ || trace_fh_ || aln_pending_) return false;
+    if (!g_ && !device_file_tried_) {
+        device_file_tried_ = true;
+        if (try_device_file()) {
+            device_file_ = true;
+            return true;
+        }
+    }
     // One GPU: the device can decode the records itself (ipx_push_bam); this thread then only cuts the inflated
     // blocks into runs of whole records and copies them to pinned memory (0.13 s for the 2.3 GB of a 10 M-record
     // BAM).  IPX_DEVICE_PARSE=1 asks for it, 0 forbids it; unasked it is used where the feeder below would be:
@@ -374,6 +478,7 @@ bool JunctionsExtractor::use_feeder() {
 static const size_t RAW_BATCH_BYTES = (size_t)96 << 20;
 
 bool JunctionsExtractor::feed_target(int32_t target_index, int32_t *other_tid) {
+    if (device_file_) return feed_target_device(target_index, other_tid);
     while (device_parse_) {
         HostBatch *b = &batch_[cur_];
         if (b->tables_lent) {                      // the push that read them completed when the other set was pushed

@@ -124,6 +124,17 @@ private:
     // ... or, on one GPU, only split here and decoded on the device (ipx_push_bam): this thread then copies
     // whole runs of records into pinned memory and never looks inside them.  IPX_DEVICE_PARSE=0 switches it off
     bool device_parse_ = false;
+    // ... or the whole file goes to the device as it is (ipx_decode_bgzf): blocks inflated and CRC-checked there,
+    // records found and decoded there; this thread walks the block headers, and afterwards the refIDs (the reader's
+    // target-by-target state machine runs over them) to push each target's slice of the device-resident batch.
+    // IPX_DEVICE_INFLATE=1 asks for it, 0 forbids it; unasked it takes BGZF files of 16 MB and more.  A file the
+    // device refuses (damage, records that straddle block ends) is read the ordinary way, which reports what is wrong.
+    bool device_file_ = false, device_file_tried_ = false;
+    ipx_batch dev_batch_{};
+    std::vector<int32_t> dev_tid_;
+    uint64_t dev_cursor_ = 0;
+    bool try_device_file();
+    bool feed_target_device(int32_t target_index, int32_t *other_tid);
     void size_raw(HostBatch &b, size_t cap_bytes);
     bool use_feeder();
     // records of target_index (BamFeeder::ANY_TARGET: all) from the feeder into the batches;

@@ -48,7 +48,9 @@ def _aux(tag):
     raise ValueError(tag)
 
 
-def sam_to_bam(sam_path, bam_path, long_cigar_threshold=65535):
+def sam_to_bam(sam_path, bam_path, long_cigar_threshold=65535, aligned=False):
+    """aligned: blocks end at record boundaries (what htslib writes: bgzf_flush_try before a record that does not fit);
+    else the stream is cut every 60000 bytes wherever that falls"""
     header_lines, names, lens, records = [], [], [], []
     with open(sam_path) as f:
         for line in f:
@@ -65,6 +67,7 @@ def sam_to_bam(sam_path, bam_path, long_cigar_threshold=65535):
     out = bytearray(b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(names)))
     for n, l in zip(names, lens):
         out += struct.pack("<I", len(n) + 1) + n.encode() + b"\0" + struct.pack("<I", l)
+    ends = [len(out)]                  # where the header and every record end
     for f in records:
         qname, flag, rname, pos, mapq, cigar, rnext, pnext, tlen, seq, qual = f[:11]
         tid = names.index(rname) if rname != "*" else -1
@@ -94,7 +97,20 @@ def sam_to_bam(sam_path, bam_path, long_cigar_threshold=65535):
                            len(cig_words), int(flag), l_seq, ntid, int(pnext) - 1, int(tlen))
         body += qname.encode() + b"\0" + struct.pack("<%dI" % len(cig_words), *cig_words) + bytes(sq) + ql + aux
         out += struct.pack("<I", len(body)) + body
+        ends.append(len(out))
     with open(bam_path, "wb") as fo:
-        for i in range(0, len(out), 60000):
-            fo.write(_bgzf_block(bytes(out[i:i + 60000])))
+        if aligned:
+            start = 0
+            for a, b in zip(ends[:-1], ends[1:]):
+                if b - start > 0xff00 and a > start:
+                    fo.write(_bgzf_block(bytes(out[start:a])))
+                    start = a
+                while b - start > 0xff00:             # a record larger than a block
+                    fo.write(_bgzf_block(bytes(out[start:start + 0xff00])))
+                    start += 0xff00
+            if len(out) > start:
+                fo.write(_bgzf_block(bytes(out[start:])))
+        else:
+            for i in range(0, len(out), 60000):
+                fo.write(_bgzf_block(bytes(out[i:i + 60000])))
         fo.write(_bgzf_block(b""))

@@ -1,5 +1,6 @@
 """GPU: the intronProspector-compatible command line of the product, byte for byte
 against the reference's golden outputs (same rules as tests/test_oracle_golden.py)."""
+import json
 import os
 import subprocess
 
@@ -20,7 +21,7 @@ def cli():
     return CLI
 
 
-def _run(cli, golden, name, outdir, inputs=None):
+def _run(cli, golden, name, outdir, inputs=None, env=None):
     opts, rule_inputs, extra, err_golden = RULES[name]
     gin = os.path.join(golden, "input")
     cmd = [cli] + [o.format(G=gin) for o in opts]
@@ -29,7 +30,7 @@ def _run(cli, golden, name, outdir, inputs=None):
     for opt, suf in outs.items():
         cmd.append("%s=%s" % (opt, os.path.join(outdir, "%s.%s" % (name, suf))))
     cmd += inputs if inputs else [os.path.join(gin, i) for i in rule_inputs]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
     assert r.returncode == 0, r.stdout.decode()
     for suf in outs.values():
         with open(os.path.join(golden, "expected", "%s.%s" % (name, suf)), "rb") as f:
@@ -257,6 +258,64 @@ def test_cli_block_parallel_bam_feeder(cli, tmp_path):
             assert os.path.getsize(tsv) > 10000
     assert len(digests) == 2, digests                   # one digest per mode, whatever the reader
 
+
+
+def test_cli_bam_inflated_on_the_device(cli, oracle_cli, golden, tmp_path):
+    """IPX_DEVICE_INFLATE=1: the BAM file goes to the device as it is (ipx_decode_bgzf) -- every BAM rule of the
+    reference's suite, a fuzzed sorted file target by target and --unsorted, a few hundred blocks; a file whose
+    records straddle block ends and damaged files are read the ordinary way and say what the ordinary reader says."""
+    import hashlib
+    env1 = dict(os.environ, IPX_DEVICE_INFLATE="1", IPX_TIMELINE="1")
+    env0 = dict(os.environ, IPX_DEVICE_INFLATE="0")
+    bam = str(tmp_path / "test_basic.bam")
+    bamio.sam_to_bam(os.path.join(golden, "input", "test_basic.sam"), bam, aligned=True)
+    for name in ("testBasic3", "testBasic4", "testBasic5"):
+        _run(cli, golden, name, str(tmp_path), inputs=[bam], env=env1)
+    # several hundred blocks, sorted and unsorted, against the host reader's output (aligned by the pass-through writer)
+    hc = os.path.join(os.path.dirname(cli), "ipx_host_check")
+    many, aligned = str(tmp_path / "many.bam"), str(tmp_path / "aligned.bam")
+    subprocess.run([hc, "make-bam", "300000", many], check=True)
+    subprocess.run([hc, "copy-aln", many, aligned], check=True)
+    for mode in ([], ["--unsorted"]):
+        digests = []
+        for env in (env1, env0):
+            tsv, bed = str(tmp_path / "o.tsv"), str(tmp_path / "o.bed")
+            r = subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed] + mode + [aligned], check=True, env=env,
+                               stderr=subprocess.PIPE)
+            digests.append(hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest())
+            if env is env1:                      # it really took the device path: one push per target (or one in all), no reading time
+                tl = json.loads([l for l in r.stderr.decode().splitlines() if "ipx_timeline" in l][-1])["ipx_timeline"]
+                assert tl["alignments"] == 300000 and tl["pushes"] <= 9, tl
+        assert digests[0] == digests[1] and os.path.getsize(tsv) > 10000
+    # fuzzed records (every aux type, odd CIGARs, unplaced reads), sorted: same bytes as the oracle's command line
+    sam, fz = str(tmp_path / "fz.sam"), str(tmp_path / "fz.bam")
+    _fuzz_sam(sam, seed=5, sorted_by_target=True)
+    bamio.sam_to_bam(sam, fz, aligned=True)
+    outs = []
+    for exe, inp, env in ((cli, fz, env1), (oracle_cli, sam, env0)):
+        tsv = str(tmp_path / "fz.tsv")
+        subprocess.run([exe, "--min-confidence-score=0.0", "--intron-calls=" + tsv, inp], check=True, env=env)
+        outs.append(open(tsv, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    # records that straddle block ends (make-bam cuts anywhere), a flipped byte, a cut file: the ordinary reader's results
+    for path, damage in ((many, None), (aligned, "flip"), (aligned, "cut")):
+        src = path
+        if damage:
+            raw = bytearray(open(path, "rb").read())
+            if damage == "flip":
+                raw[len(raw) // 2] ^= 0x55
+            else:
+                raw = raw[:len(raw) // 2]
+            src = str(tmp_path / "damaged.bam")
+            open(src, "wb").write(raw)
+        res = []
+        for env in (env1, env0):
+            tsv = str(tmp_path / "d.tsv")
+            r = subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, src], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            err = b"\n".join(l for l in r.stderr.splitlines() if b"ipx_timeline" not in l)
+            res.append((r.returncode, err, open(tsv, "rb").read() if os.path.exists(tsv) else b""))
+        assert res[0] == res[1], (damage, res[0][:2], res[1][:2])
+        assert (res[0][0] == 0) == (damage is None)
 
 
 def test_cli_device_parse_then_sam_input(cli, golden, tmp_path):

@@ -1598,6 +1598,19 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     if ((rc = ensure(h, h->bz_ws, ipx_bgzf_tables_bytes(nb)))) return rc;
     char *tb = h->bz_tab.as<char>();
     hipStream_t s = h->stream;
+    // The file's bytes are the one large copy of this call.  Pageable memory goes through the runtime's staging
+    // buffers at a fraction of the link's rate: pin the caller's pages for the duration (IPX_BGZF_REGISTER=0: don't)
+    struct Registered {
+        void *p = nullptr;
+        ~Registered() { if (p) (void)hipHostUnregister(p); }
+    } reg;
+    {
+        static const bool want = [] { const char *e = getenv("IPX_BGZF_REGISTER"); return !(e && e[0] == '0'); }();
+        if (want && f->n_bytes >= (1u << 20) && hipHostRegister((void *)f->bytes, f->n_bytes, hipHostRegisterDefault) == hipSuccess)
+            reg.p = (void *)f->bytes;
+        else
+            (void)hipGetLastError();
+    }
     HIPCHK(hipMemcpyAsync(h->bz_comp.p, f->bytes, f->n_bytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(h->bz_comp.as<char>() + f->n_bytes, 0, 16, s));
     HIPCHK(hipMemsetAsync(h->bz_out.as<char>() + T, 0, 64, s));

@@ -218,16 +218,32 @@ struct OutputFiles {
 
 // src/intronProspector.cc:330-351
 static void write_junctions(JunctionVector &juncs, float min_confidence_score, OutputFiles &output) {
+    const bool introns = output.intron_bed_fh || output.intron_bed6_fh || output.intron_call_fh;
+    // The anchor file and the intron files are sorted and formatted side by side when both are asked for (0.15 s
+    // each for 200 000 junctions): the first sort's input is the table's order either way, and the intron order has
+    // no ties (junctions.cc:108-159), so it does not depend on what the anchor sort left behind.
+    std::future<void> anchors;
     if (output.junction_bed_fh) {
-        juncs.sort_by_anchors();
-        print_anchor_bed(juncs, min_confidence_score, *output.junction_bed_fh);
+        if (introns && juncs.size() >= 10000) {
+            std::shared_ptr<JunctionVector> copy(new JunctionVector(juncs));
+            std::ostream *fh = output.junction_bed_fh.get();
+            anchors = std::async(std::launch::async, [copy, min_confidence_score, fh] {
+                copy->sort_by_anchors();
+                print_anchor_bed(*copy, min_confidence_score, *fh);
+            });
+        } else {
+            juncs.sort_by_anchors();
+            print_anchor_bed(juncs, min_confidence_score, *output.junction_bed_fh);
+        }
     }
-    if (output.intron_bed_fh || output.intron_bed6_fh || output.intron_call_fh) {
+    struct Join { std::future<void> &f; ~Join() { if (f.valid()) f.wait(); } } join{anchors};
+    if (introns) {
         juncs.sort_by_introns();
         if (output.intron_bed_fh) print_intron_bed(juncs, min_confidence_score, 9, *output.intron_bed_fh);
         if (output.intron_bed6_fh) print_intron_bed(juncs, min_confidence_score, 6, *output.intron_bed6_fh);
         if (output.intron_call_fh) print_intron_call_tsv(juncs, min_confidence_score, *output.intron_call_fh);
     }
+    if (anchors.valid()) anchors.get();              // (an exception of the anchor writer surfaces here)
 }
 
 static void output_junctions(JunctionsExtractor &extractor, float min_confidence_score, OutputFiles &output) {

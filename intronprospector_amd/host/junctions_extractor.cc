@@ -202,6 +202,16 @@ void JunctionsExtractor::open(const std::string &bam) {
         canon_tid_.push_back(first);
     }
     targets_dirty_ = true;          // handed to the device by ensure_device()
+    // A BGZF BAM file that the device is to decode whole (try_device_file) is read from here on, beside the thread
+    // that opens the device: by the time the first target is asked for, both are done.  (Read in vain if a
+    // pass-through or a trace then asks for the records one by one: they are rarely wanted of files this size.)
+    {
+        const char *e = getenv("IPX_DEVICE_INFLATE");
+        struct stat st;
+        if (!(e && e[0] == '0') && !g_ && !trace_fh_ && reader_->bgzf() && stat(bam.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
+            st.st_size >= 28 && ((e && e[0] == '1') || st.st_size >= (16 << 20)))
+            file_load_.start(bam, (size_t)st.st_size, 4);
+    }
     if (trace_fh_)          // junctions_extractor.cc:579-584 (nine names over ten columns, as there)
         *trace_fh_ << "chrom" << "\t" << "intron_start" << "\t" << "intron_end" << "\t" << "qname" << "\t" << "flag" << "\t"
                    << "strand" << "\t" << "splice_sites" << "\t" << "anchor_start" << "\t" << "anchor_end" << std::endl;
@@ -211,6 +221,7 @@ void JunctionsExtractor::open(const std::string &bam) {
 void JunctionsExtractor::open_pass_through(const std::string &bam_pass_through) {
     pass_through_.reset(new PassThroughWriter(bam_pass_through, *reader_));
     reader_->keep_raw(true);
+    file_load_.drop();              // the records are wanted one by one: the file is not decoded on the device
 }
 
 // junctions_extractor.cc:667-674: whatever the target loop left unread (unaligned reads, and
@@ -241,6 +252,7 @@ void JunctionsExtractor::close() {
         device_parse_ = false;
     }
     reader_.reset();
+    file_load_.drop();
     previous_target_ = -1;
     aln_pending_ = false;
     device_file_ = device_file_tried_ = false;
@@ -351,28 +363,59 @@ void JunctionsExtractor::flush_batch() {
     if (rc != IPX_OK) throw_last_error(rc);
 }
 
+void JunctionsExtractor::FileLoad::start(const std::string &path, size_t n_bytes, unsigned n_threads) {
+    drop();
+    void *p = nullptr;
+    if (posix_memalign(&p, (size_t)2 << 20, n_bytes + 64) != 0) return;
+    (void)madvise(p, n_bytes + 64, MADV_HUGEPAGE);
+    buf = (uint8_t *)p;
+    size = n_bytes;
+    failed = false;
+    const size_t step = ((n_bytes / n_threads) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    for (unsigned k = 0; k < n_threads; ++k) {
+        const size_t lo = std::min(n_bytes, (size_t)k * step), hi = std::min(n_bytes, lo + step);
+        if (hi == lo) break;
+        readers.emplace_back([this, path, lo, hi] {
+            const int fd = ::open(path.c_str(), O_RDONLY);
+            if (fd < 0) { failed = true; return; }
+            size_t at = lo;
+            while (at < hi && !failed) {
+                const ssize_t got = pread(fd, buf + at, std::min<size_t>(hi - at, (size_t)16 << 20), (off_t)at);
+                if (got <= 0) { failed = true; break; }
+                at += (size_t)got;
+            }
+            ::close(fd);
+        });
+    }
+}
+
+bool JunctionsExtractor::FileLoad::wait() {
+    for (std::thread &t : readers) t.join();
+    readers.clear();
+    return buf && !failed;
+}
+
+void JunctionsExtractor::FileLoad::drop() {
+    failed = true;
+    for (std::thread &t : readers) t.join();
+    readers.clear();
+    free(buf);
+    buf = nullptr;
+    size = 0;
+}
+
 // The whole BGZF file to the device (ipx_decode_bgzf).  false: not this file (too small, not asked for, damaged,
 // unaligned, no memory): the caller goes on with the reader it has, which has not consumed a record yet.
 bool JunctionsExtractor::try_device_file() {
     const char *e = getenv("IPX_DEVICE_INFLATE");
     if (e && e[0] == '0') return false;
-    const std::string &path = reader_->path();
-    const int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28 || (!(e && e[0] == '1') && st.st_size < (16 << 20))) {
-        ::close(fd);
-        return false;
-    }
-    const size_t size = (size_t)st.st_size;
-    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (map == MAP_FAILED) return false;
-    (void)madvise(map, size, MADV_SEQUENTIAL);
-    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, size};
+    if (!file_load_.buf && file_load_.readers.empty()) return false;          // open() did not start it: not this file
     const double t0 = timeline_ ? now_s() : 0.0;
+    struct Drop { FileLoad &f; ~Drop() { f.drop(); } } drop{file_load_};
+    if (!file_load_.wait()) return false;
+    const size_t size = file_load_.size;
     // the block headers (SAM spec 4.1: gzip member with a BC extra subfield that holds BSIZE - 1)
-    const uint8_t *d = (const uint8_t *)map;
+    const uint8_t *d = file_load_.buf;
     std::vector<uint64_t> pb, pe;
     std::vector<uint32_t> isz, crc;
     size_t p = 0;

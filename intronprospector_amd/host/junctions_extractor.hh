@@ -17,7 +17,9 @@
 #define IPX_HOST_JUNCTIONS_EXTRACTOR_HH
 #include <cstdint>
 #include <iostream>
+#include <atomic>
 #include <cstdio>
+#include <thread>
 #include <memory>
 #include <set>
 #include <string>
@@ -135,6 +137,17 @@ private:
     uint64_t dev_cursor_ = 0;
     bool try_device_file();
     bool feed_target_device(int32_t target_index, int32_t *other_tid);
+    // the file's bytes, read by a few threads from open() on -- while the device is still being opened
+    struct FileLoad {
+        uint8_t *buf = nullptr;
+        size_t size = 0;
+        std::vector<std::thread> readers;
+        std::atomic<bool> failed{false};
+        void start(const std::string &path, size_t n_bytes, unsigned n_threads);
+        bool wait();                       // true: buf holds the whole file
+        void drop();
+        ~FileLoad() { drop(); }
+    } file_load_;
     void size_raw(HostBatch &b, size_t cap_bytes);
     bool use_feeder();
     // records of target_index (BamFeeder::ANY_TARGET: all) from the feeder into the batches;

@@ -562,10 +562,11 @@ int ipx_set_genome_2bit(ipx_handle *h, uint32_t n_seqs, const char *const *names
         totm += ((uint64_t)lengths[i] + 31) / 32;
     }
     int rc;
-    if ((rc = ensure(h, h->d_twobit, (tot2 ? tot2 : 1) * 4))) return rc;
-    if ((rc = ensure(h, h->d_mask, (totm ? totm : 1) * 4))) return rc;
-    HIPCHK(hipMemsetAsync(h->d_twobit.p, 0, (tot2 ? tot2 : 1) * 4, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_mask.p, 0, (totm ? totm : 1) * 4, h->stream));
+    // (+ 2 spare words: ipx_motif_of reads pairs of words)
+    if ((rc = ensure(h, h->d_twobit, (tot2 + 2) * 4))) return rc;
+    if ((rc = ensure(h, h->d_mask, (totm + 2) * 4))) return rc;
+    HIPCHK(hipMemsetAsync(h->d_twobit.p, 0, (tot2 + 2) * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_mask.p, 0, (totm + 2) * 4, h->stream));
     for (uint32_t i = 0; i < n_seqs; ++i) {
         const uint64_t L = (uint64_t)lengths[i];
         if (!L) continue;

@@ -208,12 +208,8 @@ static inline uint64_t ipx_div_up(uint64_t a, uint64_t b) { return (a + b - 1) /
 
 #ifdef __HIPCC__
 // ---- splice sites on the device genome (used per junction by k_motif, per record by the scan's combiner) ----
-__device__ __forceinline__ uint32_t ipx_base2(const GenomeDev &g, uint64_t w0, int64_t p) {
-    return (g.twobit[w0 + (uint64_t)(p >> 4)] >> ((p & 15) * 2)) & 3u;
-}
-__device__ __forceinline__ uint32_t ipx_maskbit(const GenomeDev &g, uint64_t w0, int64_t p) {
-    return (g.mask[w0 + (uint64_t)(p >> 5)] >> (p & 31)) & 1u;
-}
+// two neighbouring 32-bit words at a word-aligned address, as one 8-byte load
+struct __attribute__((packed, aligned(4))) IpxWords2 { uint32_t x, y; };
 
 // splice_juncs.cc:22-26 on 2-bit codes A0 C1 G2 T3: GT/AG, GC/AG, AT/AC
 __device__ __forceinline__ bool ipx_canon4(uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1) {
@@ -237,10 +233,25 @@ __device__ __forceinline__ uint32_t ipx_motif_of(const GenomeDev &g, int32_t ski
     // acceptor [e-2,e) is fetched first (see oracle/ipxo_core.c get_splice_sites)
     if (e - 2 < 0 || e > L || s < 0 || s + 2 > L) return 0x200u;
     const uint64_t w2 = rs.word2, wm = rs.wordm;
-    const uint32_t d0 = ipx_base2(g, w2, s), d1 = ipx_base2(g, w2, s + 1);
-    const uint32_t a0 = ipx_base2(g, w2, e - 2), a1 = ipx_base2(g, w2, e - 1);
-    const uint32_t non = ipx_maskbit(g, wm, s) | ipx_maskbit(g, wm, s + 1) | ipx_maskbit(g, wm, e - 2) |
-                         ipx_maskbit(g, wm, e - 1);
+    // bases p, p + 1 lie in one 2-bit word or in two neighbours: ONE 8-byte load per pair (word-aligned is enough for a
+    // dwordx2 load; the arrays end in a spare word) instead of two 4-byte ones -- the look-up per RECORD in the scan's
+    // filter-aware combiner is bound by the number of scattered loads, not by their bytes.  The same for the mask bits.
+    auto pair2 = [&](int64_t p, uint32_t &b0, uint32_t &b1) {
+        const IpxWords2 w = *reinterpret_cast<const IpxWords2 *>(g.twobit + w2 + (uint64_t)(p >> 4));
+        const uint64_t v = (uint64_t)w.x | ((uint64_t)w.y << 32);
+        const uint32_t sh = (uint32_t)(p & 15) * 2u;
+        b0 = (uint32_t)(v >> sh) & 3u;
+        b1 = (uint32_t)(v >> (sh + 2u)) & 3u;
+    };
+    auto mask2 = [&](int64_t p) -> uint32_t {
+        const IpxWords2 w = *reinterpret_cast<const IpxWords2 *>(g.mask + wm + (uint64_t)(p >> 5));
+        const uint64_t v = (uint64_t)w.x | ((uint64_t)w.y << 32);
+        return (uint32_t)(v >> (p & 31)) & 3u;
+    };
+    uint32_t d0, d1, a0, a1;
+    pair2(s, d0, d1);
+    pair2(e - 2, a0, a1);
+    const uint32_t non = mask2(s) | mask2(e - 2);
     uint32_t m = IPX_MOTIF_PRESENT | (d0 << 6) | (d1 << 4) | (a0 << 2) | a1;
     if (non) {
         m |= IPX_MOTIF_NONACGT;

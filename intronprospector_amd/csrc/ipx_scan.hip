@@ -1082,11 +1082,14 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
 
 // ---- short CIGARs, second generation ------------------------------------------------------------
 // k_scan_short: k_scan's tile structure (one lane per alignment, RPT alignments per thread, records
-// staged in an LDS pool, ONE global atomic per tile) around the select-based walk of k_scan_long.  A
-// CIGAR of up to 8 ops arrives as two 16-byte loads instead of one dependent 4-byte load per op; the
-// eight ops run unrolled (the wave leaves when all its lanes are done); 8 ops of < 2^28 cannot carry
-// out of 32-bit offsets.  A finished junction is snapshotted; snapshots are QC'd, packed and stored for
-// all lanes of the wave at once -- when a lane is about to finish a second junction, and at the end.
+// staged in an LDS pool, ONE global atomic per tile) around closed forms for the plain spliced reads and the
+// select-based walk of k_scan_long for the rest.  A CIGAR of up to 8 ops arrives as two 16-byte loads instead
+// of one dependent 4-byte load per op; the eight ops run unrolled (the wave leaves when all its lanes are
+// done); 8 ops of < 2^28 cannot carry out of 32-bit offsets.  A finished junction is snapshotted; snapshots
+// are QC'd, packed and stored for all lanes of the wave at once -- when a lane is about to finish a second
+// junction, and at the end.  The alignments that need the walk wait in an LDS list across tiles until a
+// block's worth of them has come together (round 3: with one wave walking a tile's few while the others
+// waited at the barrier the walk was a third of a tile's time; 322 -> 281 us on S).
 // Alignments with more than 8 ops in such a batch (a few per cent at most), and whole tiles whose records
 // overflow the pool, are only LISTED (defer[], counted at IPX_CNT_DEFER) and left to k_scan_rest: with the
 // op-by-op walk inlined here the kernel needed 117 VGPRs (4 waves per SIMD), without it 87 (5 waves).
@@ -1180,8 +1183,10 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     __shared__ unsigned long long tile_slot;
     __shared__ uint4 pool_item[POOL], pool_pay[POOL];
     __shared__ uint32_t pool_n;
-    __shared__ uint16_t cx_list[BT * RPT];       // tile-local indices of the alignments that need the walk
-    __shared__ uint32_t cx_n;
+    // alignments that need the walk (batch indices): they wait here, across tiles, until a whole block's worth of
+    // them has come together -- see "the walks" below
+    __shared__ uint32_t dx_list[BT * RPT + BT];
+    __shared__ uint32_t dx_n;
     // the tile combiner (ScanParams::combine): open-addressing table of pool indices, one per distinct key
     constexpr uint32_t HT_BITS = POOL > 384 ? 10 : (POOL > 192 ? 9 : 8), HT = 1u << HT_BITS;   // >= 4/3 POOL
     constexpr uint32_t CR = (POOL + BT - 1) / BT;                                              // pool rounds per thread
@@ -1189,11 +1194,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     static_assert(HT * 3 >= POOL * 4 && POOL <= IPX_CNT_MASK, "combiner table / count word too small for the pool");
     __shared__ uint32_t ht[HT];
     __shared__ uint32_t live_n[CR][NW];
-    // Before the combiner needs its table the same words hold, for the first STASH alignments listed for the walk,
-    // what phase 1 already fetched of them (position, rank, strand / category / QC bit / CIGAR length, CIGAR offset,
-    // first four CIGAR words): phase 2 then starts from LDS instead of repeating phase 1's two dependent round trips
-    // to memory -- the walk of 7 % of a tile's alignments by one wave was a third of a tile's time.
-    constexpr uint32_t STASH = HT / 8;
+    static_assert(POOL >= 3 * BT, "a walk pass (BT alignments of at most eight ops, three records each) must fit the pool");
     unsigned long long merged_acc = 0;            // thread 0: records merged into others by this block
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint64_t n_tiles = (n + (uint64_t)BT * RPT - 1) / ((uint64_t)BT * RPT);
@@ -1212,244 +1213,275 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     };
 
     IPX_ST_DECL;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        IPX_ST_START;
-        unsigned long long my_err = IPX_ERRW_NONE;
-        if (t == 0) { pool_n = 0; cx_n = 0; }
+    unsigned long long my_err = IPX_ERRW_NONE;
+    if (t == 0) dx_n = 0;
+    __syncthreads();
+    auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
+        for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
         __syncthreads();
-        // does THIS tile combine?  (ScanParams::combine_mask: a launch that only probes combines one tile in sixteen)
-        const uint32_t comb = (p.combine_mask && ((uint32_t)tile & p.combine_mask)) ? 0u : p.combine;
-        // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one; see the
-        // comments inside.  final_pass: survivors go to the record arrays; else they close ranks inside the pool so
-        // that the tile can go on filling it (recombine: the pool may hold records an earlier pass made of several).
-        auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
-            // (until now the table's words held the walk contexts of phase 2, see STASH)
-            for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
-            __syncthreads();
-            // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
-            // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
-            // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
-            // exchange) then handles one record per key and tile.  What a group keeps is what the reduce would
-            // have made of its members anyway: the smallest order64 (with that record's strand), the smallest
-            // anchor start, the largest anchor end, the reads per category (item.w, IPX_CNT_*; it is 0 in the
-            // pool).  The first record of a key to claim a table slot OWNS the group, the others add themselves
-            // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
-            // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
-            // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
-            // active junction filter: only records that pass it may stand for others (ScanParams::combine); the
-            // others stay what they are, one read each.  The genome look-ups of all rounds go out together.
-            // fold the wave's copies of its first live key with shuffles, then claim / find the key's owner in the
-            // table and add this record (or the wave's fold) to the owner's pool entry
-            auto fold_and_insert = [&](uint32_t k, const uint4 &it, uint32_t cat, unsigned long long ord, uint32_t lo,
-                                       uint32_t hi, uint32_t cw, bool live) {
-                bool dead = false;
-                const unsigned long long lm = ipx_ballot(live);
-                if (lm) {
-                    const int f = __ffsll(lm) - 1;
-                    const uint32_t fx = __builtin_amdgcn_readlane(it.x, f), fy = __builtin_amdgcn_readlane(it.y, f),
-                                   fz = __builtin_amdgcn_readlane(it.z, f);
-                    const bool same = live && it.x == fx && it.y == fy && it.z == fz;
-                    const unsigned long long sm = ipx_ballot(same);
-                    if (__popcll(sm) >= 8) {
-                        // In a pile-up the first lane usually holds the extremes already (pool slots follow the
-                        // reads' order, copies of one key share the position and mostly the anchors): a compare and
-                        // a ballot per field tell, and the six-level butterflies (84 instructions for the three
-                        // fields) run only for a field some lane improves.
-                        const unsigned long long ord_f = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(ord >> 32), f) << 32) |
-                                                         __builtin_amdgcn_readlane((uint32_t)ord, f);
-                        const uint32_t lo_f = __builtin_amdgcn_readlane(lo, f), hi_f = __builtin_amdgcn_readlane(hi, f);
-                        unsigned long long o = ord_f;
-                        uint32_t l = lo_f, h = hi_f;
-                        if (ipx_ballot(same && ord < ord_f)) {
-                            o = same ? ord : ~0ull;
+        // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
+        // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
+        // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
+        // exchange) then handles one record per key and tile.  What a group keeps is what the reduce would
+        // have made of its members anyway: the smallest order64 (with that record's strand), the smallest
+        // anchor start, the largest anchor end, the reads per category (item.w, IPX_CNT_*; it is 0 in the
+        // pool).  The first record of a key to claim a table slot OWNS the group, the others add themselves
+        // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
+        // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
+        // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
+        // active junction filter: only records that pass it may stand for others (ScanParams::combine); the
+        // others stay what they are, one read each.  The genome look-ups of all rounds go out together.
+        // fold the wave's copies of its first live key with shuffles, then claim / find the key's owner in the
+        // table and add this record (or the wave's fold) to the owner's pool entry
+        auto fold_and_insert = [&](uint32_t k, const uint4 &it, uint32_t cat, unsigned long long ord, uint32_t lo,
+                                   uint32_t hi, uint32_t cw, bool live) {
+            bool dead = false;
+            const unsigned long long lm = ipx_ballot(live);
+            if (lm) {
+                const int f = __ffsll(lm) - 1;
+                const uint32_t fx = __builtin_amdgcn_readlane(it.x, f), fy = __builtin_amdgcn_readlane(it.y, f),
+                               fz = __builtin_amdgcn_readlane(it.z, f);
+                const bool same = live && it.x == fx && it.y == fy && it.z == fz;
+                const unsigned long long sm = ipx_ballot(same);
+                if (__popcll(sm) >= 8) {
+                    // In a pile-up the first lane usually holds the extremes already (pool slots follow the
+                    // reads' order, copies of one key share the position and mostly the anchors): a compare and
+                    // a ballot per field tell, and the six-level butterflies (84 instructions for the three
+                    // fields) run only for a field some lane improves.
+                    const unsigned long long ord_f = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(ord >> 32), f) << 32) |
+                                                     __builtin_amdgcn_readlane((uint32_t)ord, f);
+                    const uint32_t lo_f = __builtin_amdgcn_readlane(lo, f), hi_f = __builtin_amdgcn_readlane(hi, f);
+                    unsigned long long o = ord_f;
+                    uint32_t l = lo_f, h = hi_f;
+                    if (ipx_ballot(same && ord < ord_f)) {
+                        o = same ? ord : ~0ull;
 #pragma unroll
-                            for (int d = 32; d >= 1; d >>= 1) {
-                                const unsigned long long o2 = __shfl_xor(o, d);
-                                o = o2 < o ? o2 : o;
-                            }
-                        }
-                        if (ipx_ballot(same && lo < lo_f)) {
-                            l = same ? lo : ~0u;
-#pragma unroll
-                            for (int d = 32; d >= 1; d >>= 1) {
-                                const uint32_t l2 = __shfl_xor(l, d);
-                                l = l2 < l ? l2 : l;
-                            }
-                        }
-                        if (ipx_ballot(same && hi > hi_f)) {
-                            h = same ? hi : 0u;
-#pragma unroll
-                            for (int d = 32; d >= 1; d >>= 1) {
-                                const uint32_t h2 = __shfl_xor(h, d);
-                                h = h2 > h ? h2 : h;
-                            }
-                        }
-                        uint32_t c0, c1, c2;
-                        if (!recombine) {                                           // one read per lane: count lanes
-                            c0 = (uint32_t)__popcll(ipx_ballot(same && cat == 0u));
-                            c1 = (uint32_t)__popcll(ipx_ballot(same && cat == 1u));
-                            c2 = (uint32_t)__popcll(ipx_ballot(same && cat == 2u));
-                        } else {                                                    // lanes may stand for several reads
-                            uint32_t w01 = same ? ((cw & IPX_CNT_MASK) | (((cw >> IPX_CNT_BITS) & IPX_CNT_MASK) << 16)) : 0u;
-                            uint32_t w2 = same ? (cw >> (2 * IPX_CNT_BITS)) : 0u;
-#pragma unroll
-                            for (int d = 32; d >= 1; d >>= 1) { w01 += __shfl_xor(w01, d); w2 += __shfl_xor(w2, d); }
-                            c0 = w01 & 0xffffu; c1 = w01 >> 16; c2 = w2;
-                        }
-                        if ((int)lane == f) {
-                            ord = o; lo = l; hi = h;
-                            cw = c0 | (c1 << IPX_CNT_BITS) | (c2 << (2 * IPX_CNT_BITS));
-                        } else if (same) {
-                            live = false;
-                            dead = true;
+                        for (int d = 32; d >= 1; d >>= 1) {
+                            const unsigned long long o2 = __shfl_xor(o, d);
+                            o = o2 < o ? o2 : o;
                         }
                     }
-                }
-                if (live) {
-                    uint32_t hs = it.x * 0x9E3779B1u;
-                    hs ^= it.y * 0x85EBCA77u;
-                    hs ^= it.z * 0xC2B2AE3Du;
-                    hs ^= hs >> 15;
-                    hs = (hs * 0x2C1B3C6Du) >> (32 - HT_BITS);
-                    uint32_t owner = k;
-                    for (;;) {
-                        const uint32_t o = atomicCAS(&ht[hs], HT_EMPTY, k);
-                        if (o == HT_EMPTY) break;                                   // the slot is mine: I own the key
-                        const uint4 ko = pool_item[o];
-                        if (ko.x == it.x && ko.y == it.y && ko.z == it.z) { owner = o; break; }
-                        hs = (hs + 1u) & (HT - 1u);
-                    }
-                    atomicAdd(&pool_item[owner].w, cw);
-                    atomicMin(reinterpret_cast<unsigned long long *>(&pool_pay[owner]), ord);
-                    atomicMin(&pool_pay[owner].z, lo);
-                    atomicMax(&pool_pay[owner].w, hi);
-                    dead = owner != k;
-                }
-                if (dead) pool_item[k].w = REC_DEAD;       // nobody adds to a record that owns nothing
-            };
-            uint4 it_s[CR];
-            unsigned long long ord_s[CR];
-            uint32_t lo_s[CR], hi_s[CR], cw_s[CR], cat_s[CR];
-            bool live_s[CR];
-            bool pass_r[CR];
+                    if (ipx_ballot(same && lo < lo_f)) {
+                        l = same ? lo : ~0u;
 #pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                const uint32_t k = r * BT + t;
-                pass_r[r] = true;
-                if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
-                if (p.combine == 2u && k < total) {
-                    const uint4 it = pool_item[k];
-                    const uint32_t px = pool_pay[k].x;
-                    const KeyParts kp = unpack_key(it, p.key);
-                    const uint32_t m = ipx_motif_of(p.genome, p.skip_missing, kp.rank, kp.start, kp.end);
-                    pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
+                        for (int d = 32; d >= 1; d >>= 1) {
+                            const uint32_t l2 = __shfl_xor(l, d);
+                            l = l2 < l ? l2 : l;
+                        }
+                    }
+                    if (ipx_ballot(same && hi > hi_f)) {
+                        h = same ? hi : 0u;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) {
+                            const uint32_t h2 = __shfl_xor(h, d);
+                            h = h2 > h ? h2 : h;
+                        }
+                    }
+                    uint32_t c0, c1, c2;
+                    if (!recombine) {                                           // one read per lane: count lanes
+                        c0 = (uint32_t)__popcll(ipx_ballot(same && cat == 0u));
+                        c1 = (uint32_t)__popcll(ipx_ballot(same && cat == 1u));
+                        c2 = (uint32_t)__popcll(ipx_ballot(same && cat == 2u));
+                    } else {                                                    // lanes may stand for several reads
+                        uint32_t w01 = same ? ((cw & IPX_CNT_MASK) | (((cw >> IPX_CNT_BITS) & IPX_CNT_MASK) << 16)) : 0u;
+                        uint32_t w2 = same ? (cw >> (2 * IPX_CNT_BITS)) : 0u;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) { w01 += __shfl_xor(w01, d); w2 += __shfl_xor(w2, d); }
+                        c0 = w01 & 0xffffu; c1 = w01 >> 16; c2 = w2;
+                    }
+                    if ((int)lane == f) {
+                        ord = o; lo = l; hi = h;
+                        cw = c0 | (c1 << IPX_CNT_BITS) | (c2 << (2 * IPX_CNT_BITS));
+                    } else if (same) {
+                        live = false;
+                        dead = true;
+                    }
                 }
             }
+            if (live) {
+                uint32_t hs = it.x * 0x9E3779B1u;
+                hs ^= it.y * 0x85EBCA77u;
+                hs ^= it.z * 0xC2B2AE3Du;
+                hs ^= hs >> 15;
+                hs = (hs * 0x2C1B3C6Du) >> (32 - HT_BITS);
+                uint32_t owner = k;
+                for (;;) {
+                    const uint32_t o = atomicCAS(&ht[hs], HT_EMPTY, k);
+                    if (o == HT_EMPTY) break;                                   // the slot is mine: I own the key
+                    const uint4 ko = pool_item[o];
+                    if (ko.x == it.x && ko.y == it.y && ko.z == it.z) { owner = o; break; }
+                    hs = (hs + 1u) & (HT - 1u);
+                }
+                atomicAdd(&pool_item[owner].w, cw);
+                atomicMin(reinterpret_cast<unsigned long long *>(&pool_pay[owner]), ord);
+                atomicMin(&pool_pay[owner].z, lo);
+                atomicMax(&pool_pay[owner].w, hi);
+                dead = owner != k;
+            }
+            if (dead) pool_item[k].w = REC_DEAD;       // nobody adds to a record that owns nothing
+        };
+        uint4 it_s[CR];
+        unsigned long long ord_s[CR];
+        uint32_t lo_s[CR], hi_s[CR], cw_s[CR], cat_s[CR];
+        bool live_s[CR];
+        bool pass_r[CR];
+#pragma unroll
+        for (uint32_t r = 0; r < CR; ++r) {
+            const uint32_t k = r * BT + t;
+            pass_r[r] = true;
+            if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
+            if (p.combine == 2u && k < total) {
+                const uint4 it = pool_item[k];
+                const uint32_t px = pool_pay[k].x;
+                const KeyParts kp = unpack_key(it, p.key);
+                const uint32_t m = ipx_motif_of(p.genome, p.skip_missing, kp.rank, kp.start, kp.end);
+                pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < CR; ++r) {
+            if (r * BT >= total) continue;
+            const uint32_t k = r * BT + t;
+            bool live = k < total;
+            uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);
+            if (live) { it = pool_item[k]; py = pool_pay[k]; }
+            const uint32_t cat = py.x & 3u;
+            live = live && cat != 3u;
+            if (live && !pass_r[r]) {
+                live = false;
+                pool_item[k].w = IPX_CNT_ONE(cat);
+            }
+            unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
+            // a record that an earlier combine of this tile made of several brings their counts along
+            uint32_t lo = py.z, hi = py.w, cw = (recombine && it.w) ? it.w : IPX_CNT_ONE(cat);
+            if (recombine) {
+                if (live) pool_item[k].w = 0;             // the owners' count words start from nothing again
+                it_s[r] = it; lo_s[r] = lo; hi_s[r] = hi; cw_s[r] = cw; ord_s[r] = ord; live_s[r] = live; cat_s[r] = cat;
+                continue;
+            }
+            fold_and_insert(k, it, cat, ord, lo, hi, cw, live);
+        }
+        if (recombine) {
+            __syncthreads();                               // every count word of the pool is zero now
 #pragma unroll
             for (uint32_t r = 0; r < CR; ++r) {
                 if (r * BT >= total) continue;
-                const uint32_t k = r * BT + t;
-                bool live = k < total;
-                uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);
-                if (live) { it = pool_item[k]; py = pool_pay[k]; }
-                const uint32_t cat = py.x & 3u;
-                live = live && cat != 3u;
-                if (live && !pass_r[r]) {
-                    live = false;
-                    pool_item[k].w = IPX_CNT_ONE(cat);
-                }
-                unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
-                // a record that an earlier combine of this tile made of several brings their counts along
-                uint32_t lo = py.z, hi = py.w, cw = (recombine && it.w) ? it.w : IPX_CNT_ONE(cat);
-                if (recombine) {
-                    if (live) pool_item[k].w = 0;             // the owners' count words start from nothing again
-                    it_s[r] = it; lo_s[r] = lo; hi_s[r] = hi; cw_s[r] = cw; ord_s[r] = ord; live_s[r] = live; cat_s[r] = cat;
-                    continue;
-                }
-                fold_and_insert(k, it, cat, ord, lo, hi, cw, live);
+                fold_and_insert(r * BT + t, it_s[r], cat_s[r], ord_s[r], lo_s[r], hi_s[r], cw_s[r], live_s[r]);
             }
-            if (recombine) {
-                __syncthreads();                               // every count word of the pool is zero now
+        }
+        __syncthreads();
+        // survivors close ranks: position = survivors before it in pool order
+        uint32_t pos_r[CR];
+        bool live_r[CR];
 #pragma unroll
-                for (uint32_t r = 0; r < CR; ++r) {
-                    if (r * BT >= total) continue;
-                    fold_and_insert(r * BT + t, it_s[r], cat_s[r], ord_s[r], lo_s[r], hi_s[r], cw_s[r], live_s[r]);
-                }
+        for (uint32_t r = 0; r < CR; ++r) {
+            const uint32_t k = r * BT + t;
+            live_r[r] = k < total && pool_item[k].w != REC_DEAD;
+            const unsigned long long m = ipx_ballot(live_r[r]);
+            pos_r[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0) live_n[r][wave] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        uint32_t n_out = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < CR; ++r)
+#pragma unroll
+            for (uint32_t w = 0; w < NW; ++w) {
+                const uint32_t c = live_n[r][w];
+#pragma unroll
+                for (uint32_t r2 = 0; r2 < CR; ++r2)
+                    if (r < r2 || (r == r2 && w < wave)) pos_r[r2] += c;
+                n_out += c;
             }
-            __syncthreads();
-            // survivors close ranks: position = survivors before it in pool order
-            uint32_t pos_r[CR];
-            bool live_r[CR];
+        if (!final_pass) {
+            // make room: survivors move to the front of the pool, the table is emptied, the tile goes on
+            uint4 it2[CR], py2[CR];
 #pragma unroll
             for (uint32_t r = 0; r < CR; ++r) {
                 const uint32_t k = r * BT + t;
-                live_r[r] = k < total && pool_item[k].w != REC_DEAD;
-                const unsigned long long m = ipx_ballot(live_r[r]);
-                pos_r[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (lane == 0) live_n[r][wave] = (uint32_t)__popcll(m);
+                if (live_r[r]) { it2[r] = pool_item[k]; py2[r] = pool_pay[k]; }
             }
             __syncthreads();
-            uint32_t n_out = 0;
 #pragma unroll
             for (uint32_t r = 0; r < CR; ++r)
-#pragma unroll
-                for (uint32_t w = 0; w < NW; ++w) {
-                    const uint32_t c = live_n[r][w];
-#pragma unroll
-                    for (uint32_t r2 = 0; r2 < CR; ++r2)
-                        if (r < r2 || (r == r2 && w < wave)) pos_r[r2] += c;
-                    n_out += c;
-                }
-            if (!final_pass) {
-                // make room: survivors move to the front of the pool, the table is emptied, the tile goes on
-                uint4 it2[CR], py2[CR];
-#pragma unroll
-                for (uint32_t r = 0; r < CR; ++r) {
-                    const uint32_t k = r * BT + t;
-                    if (live_r[r]) { it2[r] = pool_item[k]; py2[r] = pool_pay[k]; }
-                }
-                __syncthreads();
-#pragma unroll
-                for (uint32_t r = 0; r < CR; ++r)
-                    if (live_r[r]) { pool_item[pos_r[r]] = it2[r]; pool_pay[pos_r[r]] = py2[r]; }
-                if (t == 0) {
-                    pool_n = n_out;
-                    merged_acc += total - n_out;
-                }
-                __syncthreads();
-                return;
-            }
+                if (live_r[r]) { pool_item[pos_r[r]] = it2[r]; pool_pay[pos_r[r]] = py2[r]; }
             if (t == 0) {
-                tile_slot = n_out ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)n_out) : 0ull;
+                pool_n = n_out;
                 merged_acc += total - n_out;
             }
             __syncthreads();
-            const uint64_t slot = tile_slot;
+            return;
+        }
+        if (t == 0) {
+            tile_slot = n_out ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)n_out) : 0ull;
+            merged_acc += total - n_out;
+        }
+        __syncthreads();
+        const uint64_t slot = tile_slot;
 #pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                const uint32_t k = r * BT + t;
-                const uint64_t idx = append_index(p, stripe, slot + pos_r[r]);
-                if (live_r[r] && idx < capacity) {
+        for (uint32_t r = 0; r < CR; ++r) {
+            const uint32_t k = r * BT + t;
+            const uint64_t idx = append_index(p, stripe, slot + pos_r[r]);
+            if (live_r[r] && idx < capacity) {
+                uint4 it = pool_item[k];
+                cnts[idx] = it.w;
+                it.w = (uint32_t)idx;
+                items[idx] = it;
+                pays[idx] = pool_pay[k];
+                digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
+                kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
+            }
+        }
+    };
+
+    // the tile's records -> record arrays (total <= POOL)
+    auto store_pool = [&](const uint32_t total, const uint32_t comb, const bool recombined) {
+        if (!comb) {
+            if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
+            __syncthreads();
+            const uint64_t slot = tile_slot;
+            for (uint32_t k = t; k < total; k += BT) {
+                const uint64_t idx = append_index(p, stripe, slot + k);
+                if (idx < capacity) {
                     uint4 it = pool_item[k];
-                    cnts[idx] = it.w;
                     it.w = (uint32_t)idx;
                     items[idx] = it;
-                    pays[idx] = pool_pay[k];
+                    const uint4 py = pool_pay[k];
+                    pays[idx] = py;
+                    cnts[idx] = IPX_CNT_ONE(py.x & 3u);
                     digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
                     kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                     kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
                 }
             }
-        };
+        } else {
+            combine_pool(total, true, recombined);
+        }
+    };
+
+    // ---- the walks.  An alignment without a closed form (S: 7 %, i.e. ~36 of a tile's 512) runs the select-based
+    // walk of k_scan_long, eight unrolled steps.  A wave runs the walk for all its lanes or for none, and while ONE
+    // wave walked a tile's few the block's other waves waited at the barrier: that was a third of a tile's time.  So
+    // the listed alignments WAIT, across tiles, until BT of them have come together; then every wave of the block
+    // walks 64 of them into an empty pool (at most three records from eight ops: 3 BT <= POOL, it cannot overflow),
+    // which is combined and stored like a tile's.  What phase 1 had fetched of them is fetched again (two dependent
+    // round trips per pass instead of per tile).
+    uint32_t comb = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        IPX_ST_START;
+        if (t == 0) pool_n = 0;
+        __syncthreads();
+        // does THIS tile combine?  (ScanParams::combine_mask: a launch that only probes combines one tile in sixteen)
+        comb = (p.combine_mask && ((uint32_t)tile & p.combine_mask)) ? 0u : p.combine;
         bool recombined = false;                 // (block-uniform) an early combine made room in this tile
-        // Phase 1, every alignment of the tile: the plain spliced reads "aM nN bM" (two thirds of short-read data)
-        // and "aM nN bM nN cM" (most of the rest) have closed forms -- one or two junctions, anchors a, b, c, no
-        // counters.  Everything else is only LISTED here and walked in phase 2 by as few waves as it fills: a wave
-        // runs the eight-step walk for all its lanes or for none, so packing the alignments that need it saves
-        // most of the walks.
+        // Every alignment of the tile: the plain spliced reads "aM nN bM" (two thirds of short-read data) and
+        // "aM nN bM nN cM" (most of the rest) have closed forms -- one or two junctions, anchors a, b, c, no
+        // counters.  Everything else is only LISTED here (dx_list) and walked later, see "the walks".
         // (the loads of all RPT rounds first: a round's two dependent round trips overlap the other's)
         ReadCtx c_r[RPT];
         uint32_t nc_r[RPT], off_r[RPT], w5_r[RPT];
+        bool walk_r[RPT];
         uint4 w3_r[RPT];
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r)
@@ -1470,22 +1502,28 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             const bool plain = nc == 3 && mnm;
             const bool two = nc == 5 && mnm && (w3.w & 0xfu) == 3 && (w5 & 0xfu) == 0;
             const bool walk_it = nc != 0 && !plain && !two;
-            const unsigned long long wm = ipx_ballot(walk_it);
+            // (more than 8 ops in a short-CIGAR batch: k_scan_rest's op-by-op walk)
+            const bool list_it = walk_it && nc <= 8, rest_it = walk_it && nc > 8;
+            walk_r[r] = walk_it;
+            const unsigned long long wm = ipx_ballot(list_it);
             if (wm) {
                 const int first = __ffsll(wm) - 1;
                 uint32_t base = 0;
-                if ((int)lane == first) base = atomicAdd(&cx_n, (uint32_t)__popcll(wm));
+                if ((int)lane == first) base = atomicAdd(&dx_n, (uint32_t)__popcll(wm));
                 base = __shfl(base, first);
-                if (walk_it) {
-                    const uint32_t li = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-                    cx_list[li] = (uint16_t)(r * BT + t);
-                    if (li < STASH) {
-                        uint4 *st = reinterpret_cast<uint4 *>(ht) + 2 * li;
-                        st[0] = make_uint4((uint32_t)c.pos, c.rank, c.strand | (c.cat << 8) | (c.read_rejected ? 0x400u : 0u) | ((nc < 255u ? nc : 255u) << 16),
-                                           off_r[r]);
-                        st[1] = w3;
-                    }
-                }
+                if (list_it)
+                    dx_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))] =
+                        (uint32_t)(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t);
+            }
+            const unsigned long long dm = ipx_ballot(rest_it);
+            if (dm) {
+                const int first = __ffsll(dm) - 1;
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(defer_counter(counters), (uint32_t)__popcll(dm));
+                base = __shfl(base, first);
+                if (rest_it)
+                    defer[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] =
+                        (uint32_t)(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t);
             }
             // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, then either finish(): one record, or N: the record,
             // its right anchor becomes the next left anchor, -> INTRON, M: -> RIGHT, finish(): the second record
@@ -1534,227 +1572,198 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 }
             }
         }
-        __syncthreads();
-        IPX_ST_LAP(1);                      // phase 1: CIGAR words, closed forms, pool writes, barrier
-        // Phase 2: the listed alignments, 64 per wave
-        const uint32_t n_walk = cx_n;
-        // (room for their records -- up to three from eight ops -- if the closed forms nearly filled the pool)
-        if (comb && n_walk) {
-            const uint32_t filled = pool_n;
-            if (filled + 3u * n_walk > POOL && filled <= POOL && filled > POOL / 2) {
-                combine_pool(filled, false, recombined);
-                recombined = true;
+        // ---- store the tile's records; then, while enough listed alignments wait (or, after the block's last tile,
+        // any): a walk pass into the emptied pool, stored the same way
+        const bool last_tile = tile + gridDim.x >= n_tiles;
+        bool from_walk = false;
+        uint32_t w_from = 0, w_take = 0;
+        for (;;) {
+            __syncthreads();
+            if (from_walk) IPX_ST_LAP(2); else IPX_ST_LAP(1);
+            const uint32_t total = pool_n;
+            if (total <= POOL) {
+                store_pool(total, comb, recombined);
+            } else {
+                // the pool overflowed: nothing of it is stored, the tile's alignments go to k_scan_rest (those of more
+                // than 8 ops are on its list already, those that wait for a walk pass stay where they are).  A walk
+                // pass cannot overflow (see "the walks"); if it ever did, its alignments would go the same way.
+                const uint64_t tile_base = tile * ((uint64_t)BT * RPT);
+                uint32_t mine_n = 0;
+                if (from_walk) {
+                    mine_n = t < w_take ? 1u : 0u;
+                } else {
+#pragma unroll
+                    for (uint32_t r = 0; r < RPT; ++r) {
+                        const uint64_t i = tile_base + (uint64_t)r * BT + t;
+                        mine_n += (i < n && !walk_r[r] && a_nc[i] <= 8) ? 1u : 0u;
+                    }
+                }
+                // block-wide exclusive prefix of mine_n (NW waves)
+                uint32_t incl = mine_n;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t x = __shfl_up(incl, o);
+                    if ((int)lane >= o) incl += x;
+                }
+                if (lane == 63) kb_s[wave][0] = incl;
+                __syncthreads();
+                uint32_t before = 0, all = 0;
+                for (uint32_t w = 0; w < NW; ++w) { const uint32_t sw = kb_s[w][0]; if (w < wave) before += sw; all += sw; }
+                if (t == 0) tile_slot = all ? atomicAdd(defer_counter(counters), all) : 0u;
+                __syncthreads();
+                uint32_t at = (uint32_t)tile_slot + before + incl - mine_n;
+                if (from_walk) {
+                    if (t < w_take) defer[at] = dx_list[w_from + t];
+                } else {
+#pragma unroll
+                    for (uint32_t r = 0; r < RPT; ++r) {
+                        const uint64_t i = tile_base + (uint64_t)r * BT + t;
+                        if (i < n && !walk_r[r] && a_nc[i] <= 8) defer[at++] = (uint32_t)i;
+                    }
+                }
             }
-        }
-#pragma unroll 1
-        for (uint32_t k0 = wave * 64; k0 < n_walk; k0 += BT) {
-            const bool mine = k0 + lane < n_walk;
-            const uint64_t i = tile * ((uint64_t)BT * RPT) + (mine ? cx_list[k0 + lane] : 0u);
-            ReadCtx c;
-            uint32_t nc = 0, off = 0;
-            uint4 wa = make_uint4(0, 0, 0, 0);
-            // from the stash; from memory only for what did not fit it (or when an early combine used the words)
-            const bool stashed = mine && !recombined && k0 + lane < STASH;
-            if (ipx_ballot(mine && !stashed)) {
-                unsigned long long seen = IPX_ERRW_NONE;     // gate errors were reported in phase 1
-                load_ctx(i, c, nc, off, seen);
-                if (!mine) nc = 0;
-                wa = load_cigar4(cigar, tail, n_words, (nc != 0 && nc <= 8) ? (uint64_t)off : 0ull);
-            }
-            if (stashed) {
-                const uint4 *st = reinterpret_cast<const uint4 *>(ht) + 2 * (k0 + lane);
-                const uint4 s0 = st[0];
-                c.pos = (int32_t)s0.x; c.rank = s0.y; c.strand = s0.z & 0xffu; c.cat = (s0.z >> 8) & 3u;
-                c.read_rejected = (s0.z & 0x400u) != 0;
-                c.read_index = base_read_index + i;
-                c.flag = 0; c.nhc = 0;
-                nc = s0.z >> 16;
-                off = s0.w;
-                wa = st[1];
-            }
-            const bool small = nc != 0 && nc <= 8;
-            // (a lane without a CIGAR of five to eight words reads the array's first words)
-            const uint4 wb = load_cigar4(cigar, tail, n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
-            const uint32_t pos32 = (uint32_t)c.pos;
+            __syncthreads();
+            IPX_ST_LAP(3);                      // combine + reservation + copy-out
+            const uint32_t have = dx_n;
+            if (!(have >= BT || (last_tile && have != 0u))) break;
+            const uint32_t take = have < BT ? have : BT, from = have - take;
+            w_from = from; w_take = take;
+            from_walk = true;
+            recombined = false;
+            __syncthreads();
+            if (t == 0) { pool_n = 0; dx_n = from; }
+            __syncthreads();
+                if (wave * 64u < take) {
+                    const bool mine = t < take;
+                    const uint64_t i = mine ? dx_list[from + t] : 0u;
+                    ReadCtx c;
+                    uint32_t nc = 0, off = 0;
+                    unsigned long long seen = IPX_ERRW_NONE;     // gate errors were reported when the alignment was listed
+                    load_ctx(i, c, nc, off, seen);
+                    if (!mine) nc = 0;
+                    const bool small = nc != 0 && nc <= 8;
+                    const uint4 wa = load_cigar4(cigar, tail, n_words, small ? (uint64_t)off : 0ull);
+                    // (a lane without a CIGAR of five to eight words reads the array's first words)
+                    const uint4 wb = load_cigar4(cigar, tail, n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
+                const uint32_t pos32 = (uint32_t)c.pos;
 
-            bool active = small, pending = false, fin = false;
-            uint32_t left = small ? nc : 0u;
-            uint32_t state = ST_LIMBO;
-            uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;
-            uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
-            uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;
+                bool active = small, pending = false, fin = false;
+                uint32_t left = small ? nc : 0u;
+                uint32_t state = ST_LIMBO;
+                uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;
+                uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
+                uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;
 
-            auto snap_ok = [&]() {
-                const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
-                const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
-                const uint32_t ilen = q_ie - q_is;
-                return !c.read_rejected && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
-                       (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
-                       (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
-            };
-            // QC, pack and store the waiting snapshots of the whole wave
-            auto drain = [&]() {
-                const bool pass = pending && snap_ok();
-                const unsigned long long em = ipx_ballot(pass);
-                if (em) {
-                    const uint32_t slot = pool_slot(em);
-                    if (pass) {
-                        if (slot < POOL) {
-                            ReadCtx cc = c;
-                            cc.pos = 0;
-                            uint4 it, pay;
-                            const Rec rr{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
-                                         (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
-                            pack_record_rel(p, cc, rr, pos32, ordinal, it, pay);
-                            pool_item[slot] = it;
-                            pool_pay[slot] = pay;
+                auto snap_ok = [&]() {
+                    const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
+                    const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
+                    const uint32_t ilen = q_ie - q_is;
+                    return !c.read_rejected && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
+                           (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
+                           (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
+                };
+                // QC, pack and store the waiting snapshots of the whole wave
+                auto drain = [&]() {
+                    const bool pass = pending && snap_ok();
+                    const unsigned long long em = ipx_ballot(pass);
+                    if (em) {
+                        const uint32_t slot = pool_slot(em);
+                        if (pass) {
+                            if (slot < POOL) {
+                                ReadCtx cc = c;
+                                cc.pos = 0;
+                                uint4 it, pay;
+                                const Rec rr{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
+                                             (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
+                                pack_record_rel(p, cc, rr, pos32, ordinal, it, pay);
+                                pool_item[slot] = it;
+                                pool_pay[slot] = pay;
+                            }
+                            ++ordinal;
                         }
-                        ++ordinal;
                     }
-                }
-                pending = false;
-                fin = false;
-            };
-            auto step = [&](uint32_t w) {
-                const bool run = active && left != 0;
-                const uint32_t op = w & 0xfu, len = w >> 4;
-                const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
-                const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
-                const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
-                lind += (c_id && in_l) ? len : 0u;
-                rind += (c_id && in_r) ? len : 0u;
-                const uint32_t indel2 = cur_indel + len;
-                const bool over = c_id && indel2 > p.max_anchor_indel_size;
-                const bool trig = in_r && (c_n || c_sh || over);
-                const bool last = run && left == 1;
-                if (ipx_ballot(pending && (trig || last))) drain();
-                s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
-                s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
-                pending = pending || trig;
-                const uint32_t tpn = tp + len;
-                const bool adv = c_m || c_n || (c_id && op == 2);
-                const bool bad = run && cls == 0;
-                if (ipx_ballot(bad)) {
-                    if (bad) {                                              // :312-313: the exception ends the read
-                        const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
-                        const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
-                        const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) |
-                                                     ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
-                                                     (IPX_ERRK_CIGAR << 8) | ch;
-                        my_err = e < my_err ? e : my_err;
+                    pending = false;
+                    fin = false;
+                };
+                auto step = [&](uint32_t w) {
+                    const bool run = active && left != 0;
+                    const uint32_t op = w & 0xfu, len = w >> 4;
+                    const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
+                    const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
+                    const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
+                    lind += (c_id && in_l) ? len : 0u;
+                    rind += (c_id && in_r) ? len : 0u;
+                    const uint32_t indel2 = cur_indel + len;
+                    const bool over = c_id && indel2 > p.max_anchor_indel_size;
+                    const bool trig = in_r && (c_n || c_sh || over);
+                    const bool last = run && left == 1;
+                    if (ipx_ballot(pending && (trig || last))) drain();
+                    s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
+                    s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
+                    pending = pending || trig;
+                    const uint32_t tpn = tp + len;
+                    const bool adv = c_m || c_n || (c_id && op == 2);
+                    const bool bad = run && cls == 0;
+                    if (ipx_ballot(bad)) {
+                        if (bad) {                                              // :312-313: the exception ends the read
+                            const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
+                            const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
+                            const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) |
+                                                         ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
+                                                         (IPX_ERRK_CIGAR << 8) | ch;
+                            my_err = e < my_err ? e : my_err;
+                        }
                     }
-                }
-                const bool n_r = c_n && in_r, n_lr = c_n && (in_l || in_r);
-                const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
-                const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
-                const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
-                is = n_lr ? tp : is;
-                as = as2;
-                ie = ie2;
-                ae = c_m ? tpn : ae;
-                uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);
-                uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;
-                lind = n_r ? rind : lind;
-                rind = n_r ? 0u : rind;
-                state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
-                const bool x = c_m && op == 8;
-                lmm2 += (x && state == ST_LEFT) ? len : 0u;
-                rmm2 += (x && state == ST_RIGHT) ? len : 0u;
-                lmm = lmm2;
-                rmm = rmm2;
-                cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
-                tp = adv ? tpn : tp;
-                fin = fin || (last && !bad && state == ST_RIGHT);   // finish(): never together with `trig`; kept until the drain
-                pending = pending || fin;
-                left -= run ? 1u : 0u;
-                active = run && !last && !bad;
-            };
-            step(wa.x);
-            step(wa.y);
-            if (ipx_ballot(active)) step(wa.z);
-            if (ipx_ballot(active)) step(wa.w);
-            if (ipx_ballot(active)) step(wb.x);
-            if (ipx_ballot(active)) step(wb.y);
-            if (ipx_ballot(active)) step(wb.z);
-            if (ipx_ballot(active)) step(wb.w);
-            if (ipx_ballot(pending)) drain();
-            // CIGARs of more than 8 ops in a short-CIGAR batch: listed for k_scan_rest's op-by-op walk
-            const unsigned long long dm = ipx_ballot(nc > 8);
-            if (dm) {
-                const int first = __ffsll(dm) - 1;
-                uint32_t base = 0;
-                if ((int)lane == first) base = atomicAdd(defer_counter(counters), (uint32_t)__popcll(dm));
-                base = __shfl(base, first);
-                if (nc > 8) defer[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = (uint32_t)i;
+                    const bool n_r = c_n && in_r, n_lr = c_n && (in_l || in_r);
+                    const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
+                    const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
+                    const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
+                    is = n_lr ? tp : is;
+                    as = as2;
+                    ie = ie2;
+                    ae = c_m ? tpn : ae;
+                    uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);
+                    uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;
+                    lind = n_r ? rind : lind;
+                    rind = n_r ? 0u : rind;
+                    state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
+                    const bool x = c_m && op == 8;
+                    lmm2 += (x && state == ST_LEFT) ? len : 0u;
+                    rmm2 += (x && state == ST_RIGHT) ? len : 0u;
+                    lmm = lmm2;
+                    rmm = rmm2;
+                    cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
+                    tp = adv ? tpn : tp;
+                    fin = fin || (last && !bad && state == ST_RIGHT);   // finish(): never together with `trig`; kept until the drain
+                    pending = pending || fin;
+                    left -= run ? 1u : 0u;
+                    active = run && !last && !bad;
+                };
+                step(wa.x);
+                step(wa.y);
+                if (ipx_ballot(active)) step(wa.z);
+                if (ipx_ballot(active)) step(wa.w);
+                if (ipx_ballot(active)) step(wb.x);
+                if (ipx_ballot(active)) step(wb.y);
+                if (ipx_ballot(active)) step(wb.z);
+                if (ipx_ballot(active)) step(wb.w);
+                if (ipx_ballot(pending)) drain();
             }
         }
-        __syncthreads();
-        const uint32_t total = pool_n;
-        IPX_ST_LAP(2);                      // phase 2: walks
-        if (total <= POOL && !comb) {
-            if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
-            __syncthreads();
-            const uint64_t slot = tile_slot;
-            for (uint32_t k = t; k < total; k += BT) {
-                const uint64_t idx = append_index(p, stripe, slot + k);
-                if (idx < capacity) {
-                    uint4 it = pool_item[k];
-                    it.w = (uint32_t)idx;
-                    items[idx] = it;
-                    const uint4 py = pool_pay[k];
-                    pays[idx] = py;
-                    cnts[idx] = IPX_CNT_ONE(py.x & 3u);
-                    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
-                    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
-                    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
-                }
-            }
-        } else if (total <= POOL) {
-            combine_pool(total, true, recombined);
-        } else {
-            // the pool overflowed: nothing of it is stored, the tile's alignments go to k_scan_rest (those
-            // of more than 8 ops are on its list already)
-            const uint64_t tile_base = tile * ((uint64_t)BT * RPT);
-            uint32_t mine_n = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < RPT; ++r) {
-                const uint64_t i = tile_base + (uint64_t)r * BT + t;
-                mine_n += (i < n && a_nc[i] <= 8) ? 1u : 0u;
-            }
-            // block-wide exclusive prefix of mine_n (NW waves)
-            uint32_t incl = mine_n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t x = __shfl_up(incl, o);
-                if ((int)lane >= o) incl += x;
-            }
-            if (lane == 63) kb_s[wave][0] = incl;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
-            for (uint32_t w = 0; w < NW; ++w) { const uint32_t sw = kb_s[w][0]; if (w < wave) before += sw; all += sw; }
-            if (t == 0) tile_slot = all ? atomicAdd(defer_counter(counters), all) : 0u;
-            __syncthreads();
-            uint32_t at = (uint32_t)tile_slot + before + incl - mine_n;
-#pragma unroll
-            for (uint32_t r = 0; r < RPT; ++r) {
-                const uint64_t i = tile_base + (uint64_t)r * BT + t;
-                if (i < n && a_nc[i] <= 8) defer[at++] = (uint32_t)i;
-            }
-        }
+#ifdef IPX_SCAN_STATS
+        ++st_tiles;
+#endif
+    }
+    {
         unsigned long long e = my_err;
         for (int d = 32; d >= 1; d >>= 1) {
             const unsigned long long o = __shfl_xor(e, d);
             e = o < e ? o : e;
         }
         if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
-        __syncthreads();
-        IPX_ST_LAP(3);                      // combine + reservation + copy-out
-#ifdef IPX_SCAN_STATS
-        ++st_tiles;
-#endif
     }
 #ifdef IPX_SCAN_STATS
-    if (t == 0 && (blockIdx.x % 199) == 0)
+    if (t == 0 && (blockIdx.x % 199) == 0 && st_tiles)
         printf("block %u: %u tiles; cycles per tile: attributes %llu, phase 1 %llu, walks %llu, combine + copy-out %llu\n", blockIdx.x,
                st_tiles, st_ph[0] / st_tiles, st_ph[1] / st_tiles, st_ph[2] / st_tiles, st_ph[3] / st_tiles);
 #endif

@@ -1480,7 +1480,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         // counters.  Everything else is only LISTED here (dx_list) and walked later, see "the walks".
         // (the loads of all RPT rounds first: a round's two dependent round trips overlap the other's)
         ReadCtx c_r[RPT];
-        uint32_t nc_r[RPT], off_r[RPT], w5_r[RPT];
+        uint32_t nc_r[RPT], off_r[RPT];
+        uint4 wb_r[RPT];
         bool walk_r[RPT];
         uint4 w3_r[RPT];
 #pragma unroll
@@ -1490,18 +1491,33 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
             w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
-            w5_r[r] = nc_r[r] == 5 ? cigar[(uint64_t)off_r[r] + 4] : 0u;      // off + nc <= n_words was checked
+            wb_r[r] = (nc_r[r] >= 5 && nc_r[r] <= 7) ? load_cigar4(cigar, tail, n_words, (uint64_t)off_r[r] + 4)       // off + nc <= n_words was checked
+                                                     : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
             const ReadCtx &c = c_r[r];
             const uint32_t nc = nc_r[r];
             const uint4 w3 = w3_r[r];
-            const uint32_t w5 = w5_r[r];
-            const bool mnm = (w3.x & 0xfu) == 0 && (w3.y & 0xfu) == 3 && (w3.z & 0xfu) == 0;
-            const bool plain = nc == 3 && mnm;
-            const bool two = nc == 5 && mnm && (w3.w & 0xfu) == 3 && (w5 & 0xfu) == 0;
-            const bool walk_it = nc != 0 && !plain && !two;
+            const uint4 wb = wb_r[r];
+            // One clip (S or H) in front and one at the end change nothing: a clip leaves the walk in LIMBO, where it
+            // starts, and ends a right anchor exactly as the end of the alignment does (junctions_extractor.cc:306-311,
+            // 278-282) -- so "xS aM nN bM yS" and the two-junction form with clips are the closed forms of what is left
+            // without them (real short-read data: one alignment in ten is clipped).
+            const bool lead = nc >= 4 && (w3.x & 0xeu) == 4u;
+            const uint32_t e0 = lead ? w3.y : w3.x, e1 = lead ? w3.z : w3.y, e2 = lead ? w3.w : w3.z, e3 = lead ? wb.x : w3.w,
+                           e4 = lead ? wb.y : wb.x, e5 = lead ? wb.z : wb.y;
+            const uint32_t m = nc - (lead ? 1u : 0u);
+            const bool mnm = (e0 & 0xfu) == 0 && (e1 & 0xfu) == 3 && (e2 & 0xfu) == 0;
+            const bool nm2 = (e3 & 0xfu) == 3 && (e4 & 0xfu) == 0;
+            const bool plain = mnm && (m == 3 || (m == 4 && (e3 & 0xeu) == 4u));
+            const bool two = mnm && nm2 && (m == 5 || (m == 6 && (e5 & 0xeu) == 4u));
+            // up to four ops, none of them N (or one the walk throws on, :312-313): nothing to find -- the clipped and
+            // the gapped unspliced reads of real data ("90M 10S", "40M 1D 60M"), which otherwise all queue for a walk
+            const uint32_t okm = 0x1b7u;                               // M I D S H = X
+            const bool dull = nc <= 4 && ((okm >> (w3.x & 0xfu)) & (okm >> (w3.y & 0xfu)) & 1u) != 0u &&
+                              (nc < 3 || ((okm >> (w3.z & 0xfu)) & 1u) != 0u) && (nc < 4 || ((okm >> (w3.w & 0xfu)) & 1u) != 0u);
+            const bool walk_it = nc != 0 && !plain && !two && !dull;
             // (more than 8 ops in a short-CIGAR batch: k_scan_rest's op-by-op walk)
             const bool list_it = walk_it && nc <= 8, rest_it = walk_it && nc > 8;
             walk_r[r] = walk_it;
@@ -1528,7 +1544,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, then either finish(): one record, or N: the record,
             // its right anchor becomes the next left anchor, -> INTRON, M: -> RIGHT, finish(): the second record
             // (junctions_extractor.cc:208-254,278-282).  Five lengths below 2^28 cannot leave 32 bits.
-            const uint32_t a = w3.x >> 4, n1 = w3.y >> 4, b = w3.z >> 4, n2 = w3.w >> 4, c5 = w5 >> 4;
+            const uint32_t a = e0 >> 4, n1 = e1 >> 4, b = e2 >> 4, n2 = e3 >> 4, c5 = e4 >> 4;
             const bool pass1 = (plain || two) && !c.read_rejected && n1 >= p.min_intron_length && n1 <= p.max_intron_length &&
                                a >= p.min_anchor_length && b >= p.min_anchor_length;     // junction_qc :392-397
             const bool pass2 = two && !c.read_rejected && n2 >= p.min_intron_length && n2 <= p.max_intron_length &&

@@ -385,6 +385,56 @@ def test_striped_append_with_uneven_stripes_and_capacity_retry():
     o.close()
 
 
+def test_clipped_and_unspliced_short_cigars(monkeypatch):
+    """k_scan_short's phase 1 beyond "aM nN bM": one S or H clip in front and / or at the end keeps the closed forms;
+    up to four ops without an N are dropped without a walk (unless one of them is an op the walk throws on); everything
+    else -- two clips in a row, = and X, indels next to introns -- waits for a walk pass.  All of it against the oracle,
+    in sorted order, several tiles' worth, with min-anchor / intron limits that reject some."""
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")
+    templates = ["aSbMcNdM", "aMbNcMdS", "aHbMcNdMeS", "aSbMcNdMeH", "aMbNcMdNeM", "aSbMcNdMeNfM", "aMbNcMdNeMfS",
+                 "aHbMcNdMeNfMgS", "aHbSbMcNdM", "aMbNcMdSeH", "aMbS", "aSbM", "aSbMcS", "aMbDcM", "aMbIcM", "aMbDcMdS",
+                 "aMbNcM", "a=bNcM", "aMbNcX", "aSbMcNdMeIfM", "aMbNcN", "aNbMcNdM", "aSbNcMdNeM", "aMbNcMdNeMfNgMhS",
+                 "aSbMcNdMeNfMgNhM", "aMbScNdM", "aMbHcM", "aM1DbMcNdM"]
+    rng = np.random.default_rng(407)
+    n = 60_000
+    words, offs, ncs = [], [], []
+    for _ in range(n):
+        tp = templates[int(rng.integers(0, len(templates)))]
+        cig = []
+        num = None
+        for ch in tp:
+            if ch.isdigit():
+                num = int(ch)
+            elif ch.islower():
+                num = None
+            else:
+                op = "MIDNSHP=XB".index(ch)
+                ln = num if num is not None else int({3: rng.choice([40, 80, 150, 900, 600_000]), 1: rng.integers(1, 5),
+                                                        2: rng.integers(1, 5)}.get(op, rng.integers(3, 45)))
+                cig.append((ln << 4) | op)
+                num = None
+        offs.append(len(words)); ncs.append(len(cig)); words.extend(cig)
+    batch = {"tid": np.sort(rng.integers(0, 3, n)).astype(np.int32), "pos": np.zeros(n, np.int32),
+             "flag": rng.choice(np.array([0, 16, 99, 147, 256], np.uint16), n), "xs": rng.choice(np.array([0, 43, 45], np.uint8), n),
+             "nh": rng.choice(np.array([0, 1, 1, 1, 3], np.uint8), n), "cigar_off": np.array(offs, np.uint32),
+             "n_cigar": np.array(ncs, np.uint32), "cigar": np.array(words, np.uint32)}
+    for t in range(3):
+        m = batch["tid"] == t
+        batch["pos"][m] = np.sort(rng.integers(1000, 200_000, int(m.sum()))).astype(np.int32)
+    names = ["chr1", "chr2", "chr3"]
+    for params in ({}, {"min_anchor_length": 12, "max_anchor_indel_size": 2, "min_intron_length": 70}):
+        dev, ora, err = _run_both(batch, names, params)
+        assert err is None and len(ora["intron_start"]) > 1000
+        helpers.compare_tables(dev, ora)
+    # an op the walk throws on, in an alignment that would otherwise be dropped unseen; the earliest one is reported
+    bad = synth.concat_batches([synth.slice_batch(batch, 0, 700), _one_read(_cig("30M6P30M")), synth.slice_batch(batch, 700, 2000),
+                                _one_read(_cig("5S30M4B"))])
+    dev, ora, err = _run_both(bad, names, {})
+    assert err is not None and err.index == 700 and err.msg == "Unknown cigar operation 'P'"
+    assert dev["error"].kind == 1 and dev["error"].read_index == 700 and dev["error"].detail == err.msg
+
+
 def test_short_cigar_tiles_that_overflow_the_record_pool(monkeypatch):
     """Three junctions per alignment: a tile of 512 alignments emits 1536 records, more than the 768 the
     LDS pool of k_scan_short holds -> the tile's alignments are listed and walked by the second stage

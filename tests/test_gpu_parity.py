@@ -740,6 +740,32 @@ def test_pile_up_tiles_fold_before_they_overflow_the_pool(cigars, monkeypatch):
     helpers.compare_tables(dev0, ora)
 
 
+def test_reduce_on_small_and_ragged_tables(tmp_path, monkeypatch):
+    """k_reduce at the edges of its chunks of 512 records: one-record and one-junction tables, tables that end inside a
+    chunk or a record after it, combined and uncombined records, no filter and the filter with fail-then-pass records
+    (modes 1 and 2), long reads."""
+    from intronprospector_amd import synth
+    for n, seed, sites in ((1, 5, 3), (70, 6, 2), (513, 7, 40), (40_000, 8, 150), (150_000, 9, 30_000)):
+        batch, names, _ = synth.short_reads(n, seed=seed, n_targets=2, target_len=3_000_000, n_sites=sites)
+        for comb in ("1", "0"):
+            monkeypatch.setenv("IPX_COMBINE", comb)
+            dev, ora, err = _run_both(batch, names, {})
+            assert err is None
+            helpers.compare_tables(dev, ora)
+    monkeypatch.delenv("IPX_COMBINE")
+    batch, names, genome = synth.short_reads(60_000, seed=31, n_targets=2, target_len=3_000_000, n_sites=900, genome=True)
+    fa = str(tmp_path / "g.fa")
+    genome.write_fasta(fa)
+    for flt in (1, 2):
+        dev, ora, err = _run_both(batch, names, {"junction_filter": flt}, genome=genome, fasta=fa)
+        assert err is None
+        helpers.compare_tables(dev, ora, _fetcher(genome))
+    lr, names, _ = synth.long_reads(600, seed=77, n_targets=2, target_len=3_000_000, n_transcripts=30)
+    dev, ora, err = _run_both(lr, names, {"max_anchor_indel_size": 36})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
 def test_records_export_needs_the_combiner_off():
     """ipx_records_export hands out single junction records: refused once records were combined, fine with
     IPX_OPT_COMBINE 0 (what the command line sets for --debug-trace and the strand tags); the option cannot change

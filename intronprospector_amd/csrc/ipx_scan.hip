@@ -1105,21 +1105,44 @@ struct AlnArrays {
     uint64_t n, n_words, base_read_index;
 };
 
-// the per-read gate (junctions_extractor.cc:536), strand and category of alignment i; nc = 0: nothing to walk
-__device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArrays &a, uint64_t i, ReadCtx &c,
-                                              uint32_t &nc, uint32_t &off, unsigned long long &err) {
+// An alignment's seven fields as they lie in the batch.  They are fetched for every lane, from a clamped index, in ONE
+// round trip: written as `if (i < n) { ...; if (passes the gate) { pos, off, nh, xs } }` the compiler sinks each load
+// into the branch that uses it and waits at the branch's end -- three dependent round trips per alignment and round
+// (flag nc tid / pos off nh xs / rank), six per tile, which was what k_scan_short's tiles spent their first 15 k cycles
+// on.  pin_raw() (an empty asm that names the registers) is where the loads of all rounds are waited for, together.
+struct RawAln {
+    int32_t tid, pos;
+    uint32_t flag, nc, off, nh, xs;
+};
+__device__ __forceinline__ RawAln load_raw_aln(const AlnArrays &a, uint64_t i_clamped) {
+    RawAln r;
+    r.tid = a.tid[i_clamped];
+    r.flag = a.flag[i_clamped];
+    r.nc = a.nc[i_clamped];
+    r.pos = a.pos[i_clamped];
+    r.off = a.off[i_clamped];
+    r.nh = a.nh[i_clamped];
+    r.xs = a.xs[i_clamped];
+    return r;
+}
+__device__ __forceinline__ void pin_raw(RawAln &r) {
+    asm volatile("" : "+v"(r.tid), "+v"(r.pos), "+v"(r.flag), "+v"(r.nc), "+v"(r.off), "+v"(r.nh), "+v"(r.xs));
+}
+// the index rank_of_tid is read at (any lane may read: a target that exists)
+__device__ __forceinline__ uint32_t rank_index(const ScanParams &p, const RawAln &r) {
+    return (uint32_t)r.tid < p.n_targets ? (uint32_t)r.tid : 0u;
+}
+
+// the per-read gate (junctions_extractor.cc:536), strand and category of alignment i from its fields; nc = 0: nothing
+// to walk.  rank: rank_of_tid[tid] (or tid itself in target scope)
+__device__ __forceinline__ void read_ctx_of(const ScanParams &p, const AlnArrays &a, uint64_t i, const RawAln &raw, uint32_t rank,
+                                            ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
     c.pos = 0; c.flag = 0; c.nhc = 0; c.rank = 0; c.strand = '.'; c.read_index = a.base_read_index + i;
     nc = 0; off = 0;
     if (i < a.n) {
-        // all seven fields at once (one round trip; fetching pos, off, nh and xs only for alignments that pass
-        // the gate made it two), then the target's rank
-        const int32_t tid = a.tid[i];
-        c.flag = a.flag[i];
-        nc = a.nc[i];
-        const int32_t pos = a.pos[i];
-        const uint32_t off_in = a.off[i];
-        const uint32_t nh = a.nh[i];
-        const uint32_t xs = a.xs[i];
+        const int32_t tid = raw.tid;
+        c.flag = raw.flag;
+        nc = raw.nc;
         // junctions_extractor.cc:536
         if (nc <= 1 || tid < 0 || (c.flag & (F_QCFAIL | F_DUP))) nc = 0;
         if (nc) {
@@ -1128,22 +1151,32 @@ __device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArra
                 err = e < err ? e : err;
                 nc = 0;
             } else {
-                c.pos = pos;
-                off = off_in;
+                c.pos = raw.pos;
+                off = raw.off;
                 if ((uint64_t)off + nc > a.n_words) {          // words outside the batch: never dereferenced
                     const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8) | 3u;
                     err = e < err ? e : err;
                     nc = 0;
                 }
-                c.nhc = nh;
-                c.rank = p.rank_is_tid ? (uint32_t)tid : a.rank_of_tid[tid];
+                c.nhc = raw.nh;
+                c.rank = rank;
                 c.strand = (p.strandness != IPX_UNSTRANDED) ? strand_from_flag(c.flag, p.strandness)
-                                                            : (xs ? xs : (uint32_t)'.');
+                                                            : (raw.xs ? raw.xs : (uint32_t)'.');
             }
         }
     }
     c.cat = read_category(c.flag, c.nhc);
     c.read_rejected = (c.flag & F_SECONDARY) || (p.exclude_multi && c.nhc == 2);
+}
+
+// one alignment (a.n != 0)
+__device__ __forceinline__ void load_read_ctx(const ScanParams &p, const AlnArrays &a, uint64_t i, ReadCtx &c,
+                                              uint32_t &nc, uint32_t &off, unsigned long long &err) {
+    RawAln raw = load_raw_aln(a, i < a.n ? i : a.n - 1);
+    pin_raw(raw);
+    uint32_t rank = (uint32_t)raw.tid;
+    if (!p.rank_is_tid && p.n_targets) rank = a.rank_of_tid[rank_index(p, raw)];
+    read_ctx_of(p, a, i, raw, rank, c, nc, off, err);
 }
 
 __device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
@@ -1484,15 +1517,30 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         uint4 wb_r[RPT];
         bool walk_r[RPT];
         uint4 w3_r[RPT];
+        {
+            RawAln raw_r[RPT];
+            uint32_t rank_r[RPT];
 #pragma unroll
-        for (uint32_t r = 0; r < RPT; ++r)
-            load_ctx(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, c_r[r], nc_r[r], off_r[r], my_err);
+            for (uint32_t r = 0; r < RPT; ++r) {
+                const uint64_t i = tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t;
+                raw_r[r] = load_raw_aln(aln, i < n ? i : n - 1);
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < RPT; ++r) pin_raw(raw_r[r]);
+#pragma unroll
+            for (uint32_t r = 0; r < RPT; ++r)
+                rank_r[r] = (!p.rank_is_tid && p.n_targets) ? rank_of_tid[rank_index(p, raw_r[r])] : (uint32_t)raw_r[r].tid;
+#pragma unroll
+            for (uint32_t r = 0; r < RPT; ++r)
+                read_ctx_of(p, aln, tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, raw_r[r], rank_r[r], c_r[r], nc_r[r], off_r[r], my_err);
+        }
         IPX_ST_LAP(0);                      // attributes arrived (the loads' issue + first use)
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
             w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
-            wb_r[r] = (nc_r[r] >= 5 && nc_r[r] <= 7) ? load_cigar4(cigar, tail, n_words, (uint64_t)off_r[r] + 4)       // off + nc <= n_words was checked
-                                                     : make_uint4(0, 0, 0, 0);
+            // (words 4..7 of the CIGARs that have them -- off + nc <= n_words was checked --, else the array's first: every
+            // lane loads, a load behind a branch is waited for at the branch's end)
+            wb_r[r] = load_cigar4(cigar, tail, n_words, (nc_r[r] >= 5 && nc_r[r] <= 7) ? (uint64_t)off_r[r] + 4 : 0ull);
         }
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
@@ -1582,6 +1630,12 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             if (r + 1 < RPT && comb) {
                 __syncthreads();
                 const uint32_t filled = pool_n;
+                // Everybody has read the count before anybody goes on adding to it.  Without this barrier (rounds 2 and
+                // 3, found with profiles/microbench/consistency_m1.py) a thread that was late to read saw the first
+                // records of the next round already counted, and in a tile that stood right at the threshold part of the
+                // block went into combine_pool -- and its barriers -- while the rest did not: one finalize in eight of
+                // the M shard lost or garbled a tile's records.
+                __syncthreads();
                 if (2u * filled + 64u > POOL && filled <= POOL) {
                     combine_pool(filled, false, false);
                     recombined = true;

@@ -570,13 +570,19 @@ __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, co
             const uint32_t rounds = bs_rounds(n);
             uint4 it[IPT];
 #pragma unroll
+            // (every lane loads, from a clamped address, and selects: behind `if (p < n)` the compiler waited for each of
+            // the IPT loads before it issued the next -- eight round trips to memory per leaf, the 5.5-9 k cycles of "load")
             for (uint32_t r = 0; r < IPT; ++r) {
                 const uint32_t p = bs_pos(wave, lane, r, rounds);
-                it[r] = make_uint4(0, 0, 0, 0);
-                if (r < rounds && p < n) {
-                    it[r] = items[(uint64_t)s + p];
-                    it[r].z &= 0xffffu;
-                }
+                const bool ok = r < rounds && p < n;
+                it[r] = items[(uint64_t)s + (ok ? p : 0u)];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < IPT; ++r) {
+                const uint32_t p = bs_pos(wave, lane, r, rounds);
+                const bool ok = r < rounds && p < n;
+                it[r].z &= 0xffffu;
+                if (!ok) it[r] = make_uint4(0, 0, 0, 0);
             }
             BS_LAP(0);                                     // bounds, loads issued (their wait falls into the next lap)
             const BsSorted bs = bs_block_sort(sh, it, n BS_ST_PASS);

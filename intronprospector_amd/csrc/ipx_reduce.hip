@@ -46,10 +46,13 @@ __device__ __forceinline__ Heads load_heads(const uint4 *__restrict__ items, uin
     h.ok = i < n;
     // the item and its predecessor as two independent loads (the second hits the lines of the first): taking the
     // predecessor from the lane below and letting lane 0 fetch its own afterwards put two load latencies in a row
+    // (both from clamped addresses, for every lane, then selected: a load behind a branch is waited for at the
+    // branch's end, and two of them in a row are two round trips)
     const bool has_prev = h.ok && i > 0;
-    const uint4 *pp = items + (has_prev ? i - 1 : 0);
-    h.it = h.ok ? items[i] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    const uint4 p = has_prev ? *pp : make_uint4(0, 0, 0, 0);
+    const uint4 it_raw = items[h.ok ? i : n - 1];
+    const uint4 p_raw = items[has_prev ? i - 1 : 0];
+    h.it = h.ok ? it_raw : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    const uint4 p = has_prev ? p_raw : make_uint4(0, 0, 0, 0);
     const uint32_t px = p.x, py = p.y, pz = p.z;
     (void)lane;
     const bool first = (i == 0);

@@ -478,16 +478,52 @@ __global__ __launch_bounds__(256) void k_bs_assign(uint4 *__restrict__ items, ui
     base[t] = off + incl - v;
     if (blockIdx.x == 0 && t == 0) *n_leaves_out = ws[0] + ws[1] + ws[2] + ws[3];
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + t; i < n; i += stride) {
-        uint4 it = items[i];
-        const uint64_t key = squeeze(it, sq);
-        const uint32_t c = bs_upper(cs, k1 - 1, key);
-        const uint32_t q = bs_upper(fine + (uint64_t)c * 256, fn[c], key);
-        const uint32_t id = base[c] + q;
-        it.z |= id << 16;
-        items[i] = it;
-        digs[i] = (uint8_t)id;
+    // Four records per thread at a time: a record's search is a chain of sixteen dependent look-ups (eight in the coarse
+    // table in LDS, eight in its range's fine table in L2), and one chain per thread left the kernel waiting -- 0.47 ms
+    // on L for 1.3 GB of traffic.  The four chains' look-ups of a step go out together; every look-up is made (from an
+    // index inside the padded table) and the range check selects, so that no load sits behind a branch.
+    constexpr uint32_t U = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u * U;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256u * U + t; i0 < n; i0 += stride) {
+        uint4 it[U];
+        uint64_t key[U];
+        uint32_t c[U], q[U], fnu[U];
+        const uint64_t *f[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * 256u;
+            it[u] = items[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { key[u] = squeeze(it[u], sq); c[u] = 0; q[u] = 0; }
+#pragma unroll
+        for (uint32_t step = 128; step; step >>= 1)
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t j = c[u] + step;                      // (j - 1 <= 254: inside cs[256])
+                const uint64_t v = cs[j - 1];
+                if (j <= k1 - 1 && v <= key[u]) c[u] = j;
+            }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { f[u] = fine + (uint64_t)c[u] * 256; fnu[u] = fn[c[u]]; }
+#pragma unroll
+        for (uint32_t step = 128; step; step >>= 1)
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t j = q[u] + step;                      // (inside the range's 256-entry row, padded with ~0)
+                const uint64_t v = f[u][j - 1];
+                if (j <= fnu[u] && v <= key[u]) q[u] = j;
+            }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * 256u;
+            if (i < n) {
+                const uint32_t id = base[c[u]] + q[u];
+                it[u].z |= id << 16;
+                items[i] = it[u];
+                digs[i] = (uint8_t)id;
+            }
+        }
     }
 }
 

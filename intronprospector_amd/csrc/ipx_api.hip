@@ -1010,6 +1010,9 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
             if ((rc = ensure(h, h->items_b, h->rec_cap * sizeof(uint4)))) return rc;
             if ((rc = ensure(h, h->dig_b, h->rec_cap + 64))) return rc;
             if ((rc = ensure(h, h->sort_ws, ws_bytes))) return rc;
+            // tot[2]: "the items are not sorted" -- raised by the bucket sort when a leaf did not fit LDS, and by k_count_heads
+            // behind EVERY sort when two neighbouring items are out of order
+            HIPCHK(hipMemsetAsync(tot + 2, 0, sizeof(uint32_t), s));
             if (by_buckets) {
                 if ((rc = ensure(h, h->bs_ws, ipx_bsort_workspace_bytes()))) return rc;
                 HIPCHK(ipx_launch_bsort(s, h->items_a.as<uint4>(), h->items_b.as<uint4>(), h->dig_a.as<uint8_t>(),
@@ -1023,20 +1026,25 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         uint32_t *chunk_j = h->sort_ws.as<uint32_t>();
         uint32_t *chunk_b = chunk_j + chunks_al;
         uint32_t *sums = chunk_b + chunks_al;
-        for (;;) {
+        for (bool second_try = false;; second_try = true) {
             SortedItems si0{h->items_a.as<uint4>(), R};
             if (resort) {
-                HIPCHK(ipx_launch_count_heads(s, si0, chunk_j, chunk_b));
+                HIPCHK(ipx_launch_count_heads(s, si0, chunk_j, chunk_b, tot + 2));
                 HIPCHK(ipx_launch_scan_u32_pair(s, chunk_j, chunk_j, chunks, tot + 0, chunk_b, chunk_b, chunks, tot + 1, sums));
             }
-            if ((rc = read_back(h, small, tot, by_buckets ? 3 : 2))) return rc;
+            if ((rc = read_back(h, small, tot, 3))) return rc;
             h->prof.collect();
             ipx_prof_mark(s, IPXK_BEGIN);
-            if (!by_buckets || small[2] == 0) break;
-            // a leaf did not fit LDS: the records are all there, keys intact, in some order -> the LSD sort
+            if (!resort || small[2] == 0) break;
+            // The items are not sorted: a leaf of the bucket sort did not fit LDS, or its ranks came out wrong (they rest on
+            // the order in which the LDS atomics of one instruction return, ipx_bsort.hip) -- the records are all there,
+            // keys intact, in some order -> the radix passes.  If THOSE leave them unsorted the device is not to be trusted.
+            if (second_try || !by_buckets)
+                return fail(h, IPX_EDEVICE, "ipx_finalize: the radix sort left the records unsorted%s%ld", "", 0);
             if (getenv("IPX_DEBUG_PLAN")) fprintf(stderr, "ipx: bucket sort overflowed a leaf, sorting %llu records by radix passes\n", (unsigned long long)R);
             by_buckets = false;
             h->bsort_skip = 15;
+            HIPCHK(hipMemsetAsync(tot + 2, 0, sizeof(uint32_t), s));
             if ((rc = lsd_sort(false, ideal))) return rc;
         }
         SortedItems si{h->items_a.as<uint4>(), R};

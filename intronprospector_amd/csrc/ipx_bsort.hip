@@ -303,17 +303,20 @@ __device__ __forceinline__ BsSorted bs_block_sort(BsShared<IPT> &sh, uint4 (&it)
 // Start-up check of the property bs_block_sort's ranking rests on (see there): random digits, few and many equal
 // ones per wave, the atomic's return value against the ballot-matched rank.  *bad counts the differences.
 __global__ __launch_bounds__(256) void k_bs_selftest(uint32_t iters, unsigned long long *bad) {
-    __shared__ uint32_t cnt[4][256];
+    // (the counters as bs_block_sort has them: two 16-bit counters per word, the digit's parity picks the half, so lanes
+    // of one instruction add DIFFERENT increments to one word -- round 3's check had a word per digit)
+    __shared__ uint32_t cnt[4][128];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     unsigned long long mism = 0;
     for (uint32_t it = 0; it < iters; ++it) {
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) cnt[wave][q * 64 + lane] = 0;
+        for (uint32_t q = 0; q < 2; ++q) cnt[wave][q * 64 + lane] = 0;
         __builtin_amdgcn_wave_barrier();
         uint32_t h = (blockIdx.x * 256u + t) * 2654435761u + it * 40503u;
         h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
         const uint32_t dig = (it & 1u) ? (h % (1u + (it >> 1) % 9u)) : (h & 255u);
-        const uint32_t r_atomic = atomicAdd(&cnt[wave][dig], 1u);
+        const uint32_t hs = (dig & 1u) * 16u;
+        const uint32_t r_atomic = (atomicAdd(&cnt[wave][dig >> 1], 1u << hs) >> hs) & 0xffffu;
         unsigned long long peers = ~0ull;
 #pragma unroll
         for (uint32_t b = 0; b < 8; ++b) {

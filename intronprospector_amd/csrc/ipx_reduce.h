@@ -31,7 +31,8 @@ struct ReduceBuffers {
 };
 
 uint64_t ipx_reduce_chunks(uint64_t n);
-hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b);
+// *unsorted (device): |= 1 when two neighbouring items are out of order
+hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b, uint32_t *unsorted);
 hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *pays, const uint32_t *cnts, const KeyLayout &kl,
                              const ReduceBuffers &rb, const GenomeDev &genome, int32_t sj_filter,
                              int32_t skip_missing, const uint32_t *tid_of_rank, Counters *counters);

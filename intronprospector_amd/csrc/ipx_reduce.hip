@@ -36,6 +36,7 @@ constexpr unsigned long long NONE64 = 0xffffffffffffffffull;
 
 struct Heads {
     bool ok, head_j, head_b;
+    bool desc;          // the item's key is SMALLER than its predecessor's: the items are not sorted
     uint4 it;
 };
 
@@ -49,7 +50,7 @@ __device__ __forceinline__ Heads load_heads(const uint4 *__restrict__ items, uin
     // (both from clamped addresses, for every lane, then selected: a load behind a branch is waited for at the
     // branch's end, and two of them in a row are two round trips)
     const bool has_prev = h.ok && i > 0;
-    const uint4 it_raw = items[h.ok ? i : n - 1];
+    const uint4 it_raw = items[h.ok ? i : (n ? n - 1 : 0)];      // (n == 0: the launcher does not launch; the index stays in range anyway)
     const uint4 p_raw = items[has_prev ? i - 1 : 0];
     h.it = h.ok ? it_raw : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     const uint4 p = has_prev ? p_raw : make_uint4(0, 0, 0, 0);
@@ -60,24 +61,32 @@ __device__ __forceinline__ Heads load_heads(const uint4 *__restrict__ items, uin
     const bool db = dj || ((px & 0xffffu) != (h.it.x & 0xffffu));
     h.head_j = h.ok && (first || dj);
     h.head_b = h.ok && (first || db);
+    h.desc = has_prev && (pz > h.it.z || (pz == h.it.z && (py > h.it.y || (py == h.it.y && px > h.it.x))));
     return h;
 }
 
+// unsorted: |= 1 when two neighbouring items are out of order.  Every sort of ipx_finalize ends here, so whatever one of
+// them rests on -- the bucket sort's leaf ranks come from the order in which LDS atomics of one instruction return
+// (ipx_bsort.hip) -- a table is never reduced from items that are not sorted: ipx_finalize sorts them again by radix
+// passes, and fails if those leave them unsorted too.
 __global__ __launch_bounds__(256) void k_count_heads(const uint4 *__restrict__ items,
                                                      uint64_t n, uint32_t *__restrict__ chunk_j,
-                                                     uint32_t *__restrict__ chunk_b) {
+                                                     uint32_t *__restrict__ chunk_b, uint32_t *__restrict__ unsorted) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t base = chunk * CHUNK;
     if (base >= n) return;
     uint32_t cj = 0, cb = 0;
+    bool desc = false;
 #pragma unroll
     for (uint32_t r = 0; r < ROUNDS; ++r) {
         const Heads h = load_heads(items, base + r * 64 + lane, n, lane);
         cj += (uint32_t)__popcll(ipx_ballot(h.head_j));
         cb += (uint32_t)__popcll(ipx_ballot(h.head_b));
+        desc = desc || h.desc;
     }
     if (lane == 0) { chunk_j[chunk] = cj; chunk_b[chunk] = cb; }
+    if (ipx_ballot(desc) && lane == 0) atomicOr(unsorted, 1u);
 }
 
 // junction / bin descriptors at the segment heads
@@ -665,9 +674,9 @@ static inline dim3 grid1d(uint64_t n, uint32_t per_block) { return dim3((uint32_
 
 uint64_t ipx_reduce_chunks(uint64_t n) { return ipx_div_up(n, CHUNK); }
 
-hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b) {
+hipError_t ipx_launch_count_heads(hipStream_t s, const SortedItems &si, uint32_t *chunk_j, uint32_t *chunk_b, uint32_t *unsorted) {
     const uint64_t chunks = ipx_div_up(si.n, CHUNK);
-    hipLaunchKernelGGL(k_count_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, chunk_j, chunk_b);
+    hipLaunchKernelGGL(k_count_heads, grid1d(chunks, 4), dim3(256), 0, s, si.items, si.n, chunk_j, chunk_b, unsorted);
     ipx_prof_mark(s, IPXK_COUNT_HEADS);
     return hipGetLastError();
 }

@@ -1,0 +1,10 @@
+cd "$GRAFT_REPO_ROOT"
+for W in S G; do
+for cfg in "prev:profiles/microbench/libipx_prev.so::" "off:intronprospector_amd/libipx.so:IPX_BUCKETS=0:IPX_GHOSTS=0" "ghosts:intronprospector_amd/libipx.so:IPX_BUCKETS=0:" "on:intronprospector_amd/libipx.so::"; do
+IFS=: read name lib e1 e2 <<< "$cfg"
+env $e1 $e2 IPX_DEBUG_PLAN=1 IPX_LIB_PATH=$PWD/$lib python bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-parity 2> gpurun_out/r4_ab5_${W}_$name.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('$W $name', round(d['ms_per_step'],4), 'recs', r.get('records_after_combine'), {k:round(v*1e3) for k,v in r['kernels_ms_per_step'].items()})"
+grep "position" gpurun_out/r4_ab5_${W}_$name.err | sort | uniq -c | head -3
+done; done

@@ -374,7 +374,9 @@ int ipx_records_partition_slots(ipx_handle *h, uint32_t n_parts, const uint64_t 
 int ipx_records_adopt_slots(ipx_handle *h, uint32_t n_slots, uint64_t slot_records, const void *slots,
                             uint64_t n_alignments, ipx_slots_info *info);
 /* Run everything the handle queues on the caller's HIP stream (hipStream_t; NULL: back to the handle's own), e.g. the
- * stream a torch.distributed collective is ordered on.  Waits for what the handle had queued before. */
+ * stream a torch.distributed collective is ordered on.  Waits for what the handle had queued before.  NULL never means
+ * the null stream: a caller that wants the legacy null stream names it, hipStreamLegacy ((hipStream_t)1) -- a handle
+ * left on its own non-blocking stream runs BESIDE the null stream, ordered against nothing queued there. */
 int ipx_use_stream(ipx_handle *h, void *hip_stream);
 
 /* The handle's pending junction records, decoded, in no particular order (sort by `order`

@@ -1601,6 +1601,16 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
                    t_st = al(t_crc + 4 * nb), t_cnt = al(t_st + 4 * nb), t_pre = al(t_cnt + 4 * (nb + 1)), t_sb = al(t_pre + 4 * (nb + 1)),
                    t_sf = al(t_sb + 8 * (nb + 1)), t_sums = al(t_sf + 8 * (nb + 1)), t_flags = al(t_sums + 4 * (ipx_div_up(nb, 4096) + 8)),
                    t_map = al(t_flags + 64), t_total = al(t_map + 4ull * f->n_tid_map);
+    // Does it fit?  The file's bytes, the inflated stream, the decoded batch (20 bytes per alignment and the CIGAR words:
+    // at most half of the stream again) and the tables all lie on the device at once.  Asked BEFORE anything is copied: a
+    // caller that hears IPX_ENOMEM reads the file through its ordinary batches.
+    {
+        size_t free_b = 0, total_b = 0;
+        const uint64_t have = h->bz_comp.cap + h->bz_out.cap + h->bz_soa.cap + h->bz_cigar.cap;      // (kept from an earlier file)
+        const uint64_t need = f->n_bytes + T + T / 2 + t_total + ipx_bgzf_tables_bytes(nb) + (64ull << 20);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > have && need - have > (uint64_t)((double)free_b * 0.9))
+            return fail(h, IPX_ENOMEM, "ipx_decode_bgzf: the file needs about %s%ld MB of device memory", "", (long)(need >> 20));
+    }
     if ((rc = ensure(h, h->bz_comp, f->n_bytes + 16))) return rc;
     if ((rc = ensure(h, h->bz_out, T + 64))) return rc;
     if ((rc = ensure(h, h->bz_tab, t_total + 256))) return rc;
@@ -1609,10 +1619,17 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     hipStream_t s = h->stream;
     // The file's bytes are the one large copy of this call.  Pageable memory goes through the runtime's staging
     // buffers at a fraction of the link's rate: pin the caller's pages for the duration (IPX_BGZF_REGISTER=0: don't)
+    // (On every way out -- the early error returns included -- the stream is waited for before the caller's buffers are
+    // let go: copies of the file's bytes and of the caller's block tables may still be under way, and the caller frees both
+    // right after a failure: advisor, round 3.)
     struct Registered {
+        hipStream_t s;
         void *p = nullptr;
-        ~Registered() { if (p) (void)hipHostUnregister(p); }
-    } reg;
+        ~Registered() {
+            (void)hipStreamSynchronize(s);
+            if (p) (void)hipHostUnregister(p);
+        }
+    } reg{s};
     {
         static const bool want = [] { const char *e = getenv("IPX_BGZF_REGISTER"); return !(e && e[0] == '0'); }();
         if (want && f->n_bytes >= (1u << 20) && hipHostRegister((void *)f->bytes, f->n_bytes, hipHostRegisterDefault) == hipSuccess)

@@ -286,6 +286,7 @@ class RecordExchanger:
         self.slotted = True              # False: always the exact exchange (tests compare both)
         self._slot_records = None        # records per slot of the slotted exchange (None: not known yet)
         self._send = self._recv = None
+        self._stream = None              # the slotted exchange's own stream (see _run_slotted)
         self.slot_overflows = 0
         self.strict = True               # look at the ranks' finalize errors at the end of every run (False: check_last())
         self._last_trouble = None
@@ -345,9 +346,31 @@ class RecordExchanger:
             ex.records_pending()                  # completes a pending push: a data error of this rank's scan surfaces at finalize
         except IpxError as exc:
             failed = ShardError.from_ipx(exc)
-        # everything below is queued on ONE stream -- the handle's kernels, torch's ops, the collectives' waits
+        # Everything below is queued on ONE stream -- the handle's kernels, torch's ops, the collectives' waits -- and that
+        # stream is the exchanger's OWN (round 4).  Round 3 took torch's current stream, which nobody had set: the legacy
+        # null stream, handle 0, which ipx_use_stream reads as "the handle's own non-blocking stream again" -- so the
+        # handle's kernels ran beside torch's, ordered against nothing: the all_to_all could read `send` while
+        # k_part_scatter wrote it, the adoption could read `recv` before the collective had filled it (the advisor's
+        # finding; no test saw it because every step resent the same batch).  A stream of our own has a handle that is
+        # not 0, is ordered after what the caller queued before (wait_stream), and the caller's stream waits for it at
+        # the end.
         staged = self.comm_device != self.device          # gloo rehearsal: the collectives run on CPU copies
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(self.device)
+        caller_stream = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(caller_stream)
+        with torch.cuda.stream(self._stream):
+            try:
+                return self._slotted_on_stream(ex, n_alignments_local, world, S, failed, staged, t0)
+            finally:
+                ex.use_stream(None)
+                caller_stream.wait_stream(self._stream)
+
+    def _slotted_on_stream(self, ex, n_alignments_local, world, S, failed, staged, t0):
+        from . import _lib as L
+        from .extractor import IpxError
         stream = torch.cuda.current_stream(self.device)
+        assert stream.cuda_stream != 0
         ex.use_stream(stream.cuda_stream)
         need = world * S * 32
         if self._send is None or self._send.numel() < need:
@@ -377,12 +400,10 @@ class RecordExchanger:
         # (what the headers said is the same on every rank -- every sender's flags reach every receiver -- so all
         # ranks take the same branch here without talking to each other)
         if info.error_order != ERR_NONE or (failed is not None):
-            ex.use_stream(None)
             agree_on_error(failed, self.group, self.comm_device)
         if info.overflow:
             self._slot_records = int(info.max_part * self.SLOT_MARGIN) + 64
             self.slot_overflows += 1
-            ex.use_stream(None)
             raise SlotOverflow(self._slot_records)
         # keep the slots a margin above what the data needs (they shrink slowly, grow at once)
         want = int(info.max_part * self.SLOT_MARGIN) + 64
@@ -422,7 +443,6 @@ class RecordExchanger:
         self._last_trouble = (parts[:, 0].min(), failed)
         if self.strict:
             self.check_last()
-        ex.use_stream(None)
         t0 = self._lap("global_ijunc", t0)
         return table, ijunc
 

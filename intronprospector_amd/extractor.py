@@ -170,8 +170,14 @@ class JunctionsExtractor:
         return info
 
     def use_stream(self, stream_ptr):
-        """queue everything on the caller's HIP stream (0 / None: the handle's own again)"""
-        self._check(self.lib.ipx_use_stream(self.h, stream_ptr or None))
+        """queue everything on the caller's HIP stream.  None: the handle's own again.  0 -- what torch calls its default
+        stream -- is the legacy null stream and is passed on as hipStreamLegacy (include/ipx.h: a null pointer means "the
+        handle's own", so the null stream has to be NAMED; round 3 read 0 as None and ran beside the stream it was asked
+        to run on)."""
+        if stream_ptr is None:
+            self._check(self.lib.ipx_use_stream(self.h, None))
+        else:
+            self._check(self.lib.ipx_use_stream(self.h, int(stream_ptr) or 1))
 
     def copy_async(self, dst_ptr, src_ptr, n_bytes):
         self._check(self.lib.ipx_copy_async(self.h, dst_ptr, src_ptr, int(n_bytes)))

@@ -118,6 +118,7 @@ void JunctionsExtractor::ensure_device() {
 JunctionsExtractor::~JunctionsExtractor() {
     if (timeline_)
         std::cerr << "{\"ipx_timeline\": {\"alignments\": " << next_read_index_ << ", \"pushes\": " << n_push_
+                  << ", \"files_decoded_on_device\": " << n_device_files_
                   << ", \"read_s\": " << t_read_ << ", \"queue_s\": " << t_queue_ << ", \"push_wait_s\": " << t_push_
                   << ", \"finalize_s\": " << t_finalize_ << ", \"table_to_host_rows_s\": " << t_table_
                   << ", \"device_create_s\": " << t_create_ << ", \"pinned_alloc_s\": " << t_alloc_
@@ -188,6 +189,39 @@ void JunctionsExtractor::throw_last_error(int status) {
     throw std::runtime_error(msg);
 }
 
+// bytes of a BGZF file that may still be decoded whole on the device (see open())
+static uint64_t device_inflate_limit() {
+    uint64_t limit = 8192ull << 20;
+    if (const char *m = getenv("IPX_DEVICE_INFLATE_MAX")) {
+        const long long v = atoll(m);
+        if (v > 0) limit = (uint64_t)v << 20;
+    }
+    // what the host can spare: MemAvailable, and under a cgroup its limit minus what is in use
+    uint64_t avail = ~0ull;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            unsigned long long kb = 0;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (uint64_t)kb << 10; break; }
+        }
+        fclose(f);
+    }
+    auto read_u64 = [](const char *path, uint64_t &out) {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char buf[64] = {0};
+        const bool ok = fgets(buf, sizeof buf, f) != nullptr && buf[0] >= '0' && buf[0] <= '9';
+        fclose(f);
+        if (ok) out = strtoull(buf, nullptr, 10);
+        return ok;
+    };
+    uint64_t cg_max = 0, cg_cur = 0;
+    if (read_u64("/sys/fs/cgroup/memory.max", cg_max) && read_u64("/sys/fs/cgroup/memory.current", cg_cur) && cg_max > cg_cur)
+        avail = std::min(avail, cg_max - cg_cur);
+    if (avail != ~0ull) limit = std::min(limit, avail / 2);
+    return limit;
+}
+
 // junctions_extractor.cc:571-586 (save_targets :564-568 appends)
 void JunctionsExtractor::open(const std::string &bam) {
     ScopeTimer scope_timer{t_open_, now_s()};
@@ -205,11 +239,16 @@ void JunctionsExtractor::open(const std::string &bam) {
     // A BGZF BAM file that the device is to decode whole (try_device_file) is read from here on, beside the thread
     // that opens the device: by the time the first target is asked for, both are done.  (Read in vain if a
     // pass-through or a trace then asks for the records one by one: they are rarely wanted of files this size.)
+    // The whole file then lies in host memory, and its bytes, what they inflate to (4-5 times as much) and the decoded
+    // batch lie on the device: that path is for files that FIT -- at most IPX_DEVICE_INFLATE_MAX megabytes (default
+    // 8192: ~60 GB on the device) and at most half of the memory this process may still take; larger files are streamed
+    // through the batches of the ordinary reader, as the reference streams them (junctions_extractor.cc:620-634).
+    // (Round 3 had no bound: a 50 GB file was read whole, in vain or until the host ran out of memory.)
     {
         const char *e = getenv("IPX_DEVICE_INFLATE");
         struct stat st;
         if (!(e && e[0] == '0') && !g_ && !trace_fh_ && reader_->bgzf() && stat(bam.c_str(), &st) == 0 && S_ISREG(st.st_mode) &&
-            st.st_size >= 28 && ((e && e[0] == '1') || st.st_size >= (16 << 20)))
+            st.st_size >= 28 && ((e && e[0] == '1') || st.st_size >= (16 << 20)) && (uint64_t)st.st_size <= device_inflate_limit())
             file_load_.start(bam, (size_t)st.st_size, 4);
     }
     if (trace_fh_)          // junctions_extractor.cc:579-584 (nine names over ten columns, as there)
@@ -455,6 +494,7 @@ bool JunctionsExtractor::try_device_file() {
     dev_tid_.resize(dev_batch_.n_alignments);
     if (!dev_tid_.empty() && ipx_copy(h_, dev_tid_.data(), dev_batch_.tid, dev_tid_.size() * sizeof(int32_t)) != IPX_OK) return false;
     dev_cursor_ = 0;
+    ++n_device_files_;
     if (timeline_) t_read_ += now_s() - t0;
     return true;
 }

@@ -157,7 +157,7 @@ private:
     // IPX_TIMELINE=1: where the wall time of the command goes (stderr, one JSON line at destruction)
     bool timeline_ = false;
     double t_read_ = 0, t_queue_ = 0, t_push_ = 0, t_finalize_ = 0, t_table_ = 0, t_create_ = 0, t_alloc_ = 0, t_born_ = 0, t_identify_ = 0, t_close_ = 0, t_getj_ = 0, t_open_ = 0;
-    uint64_t n_push_ = 0;
+    uint64_t n_push_ = 0, n_device_files_ = 0;
     uint32_t tick_ = 0;
     // finalized table of the records pushed since the last clear()
     bool table_valid_ = false;

@@ -285,8 +285,19 @@ def test_cli_bam_inflated_on_the_device(cli, oracle_cli, golden, tmp_path):
             digests.append(hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest())
             if env is env1:                      # it really took the device path: one push per target (or one in all), no reading time
                 tl = json.loads([l for l in r.stderr.decode().splitlines() if "ipx_timeline" in l][-1])["ipx_timeline"]
-                assert tl["alignments"] == 300000 and tl["pushes"] <= 9, tl
+                assert tl["alignments"] == 300000 and tl["pushes"] <= 9 and tl["files_decoded_on_device"] == 1, tl
         assert digests[0] == digests[1] and os.path.getsize(tsv) > 10000
+    # a file above IPX_DEVICE_INFLATE_MAX (megabytes) is not read whole: it goes through the ordinary reader's batches
+    # (round 4: the path had no bound, the advisor's finding) -- same bytes, and the timeline shows many pushes
+    tsv, bed = str(tmp_path / "o.tsv"), str(tmp_path / "o.bed")
+    assert os.path.getsize(aligned) > (2 << 20)
+    r = subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed, aligned], check=True, stderr=subprocess.PIPE,
+                       env=dict(env1, IPX_DEVICE_INFLATE_MAX="1"))
+    tl = json.loads([l for l in r.stderr.decode().splitlines() if "ipx_timeline" in l][-1])["ipx_timeline"]
+    assert tl["alignments"] == 300000 and tl["files_decoded_on_device"] == 0, tl
+    sorted_digest = hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest()
+    r0 = subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed, aligned], check=True, env=env0, stderr=subprocess.PIPE)
+    assert sorted_digest == hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest()
     # fuzzed records (every aux type, odd CIGARs, unplaced reads), sorted: same bytes as the oracle's command line
     sam, fz = str(tmp_path / "fz.sam"), str(tmp_path / "fz.bam")
     _fuzz_sam(sam, seed=5, sorted_by_target=True)

@@ -196,3 +196,57 @@ def test_two_ranks_raise_the_earliest_error_of_the_run(path, oracle_lib):
     everybody, expect, i0, i1 = run_workers(_error_worker, 2, (_free_port(), path), timeout=240)
     assert expect is not None and expect[1] == i0 < i1, (expect, i0, i1)
     assert everybody[0] == everybody[1] == expect, (everybody, expect)
+
+
+def test_rccl_exchange_with_a_different_batch_every_step():
+    """The slotted exchange on RCCL (one rank: the all_to_all is a device copy ordered by streams alone, no host in
+    between) with batches that DIFFER from step to step, each table against the oracle.  Round 3's rehearsals resent one
+    batch, so a step that adopted the previous step's slots, or sent slots still being written, produced the right table
+    all the same; and the exchange ran beside the stream it was asked to run on (advisor, round 3)."""
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    from intronprospector_amd.distributed import RecordExchanger, SlotOverflow, table_to_torch
+    from tests.oracle_binding import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        names = None
+        ex = None
+        xch = RecordExchanger(dev, comm_device=dev)
+        slotted = 0
+        for step, (reads, seed) in enumerate([(300_000, 71), (280_000, 72), (310_000, 73), (150_000, 74), (305_000, 75)]):
+            batch, nm, _ = synth.short_reads(reads, seed=seed, n_targets=4, target_len=9_000_000, n_sites=6000)
+            if ex is None:
+                names = nm
+                ex = ipa.JunctionsExtractor(targets=names)
+            for attempt in range(3):
+                ex.clear()
+                ex.push(batch)
+                before = xch.slot_overflows
+                try:
+                    was_slotted = xch._splitters is not None and xch._slot_records is not None
+                    table, ijunc = xch.run(ex, reads)
+                    slotted += int(was_slotted)
+                    break
+                except SlotOverflow:
+                    assert attempt < 2 and xch.slot_overflows == before + 1
+            t = table_to_torch(ex, table, "cpu")
+            ora = Oracle(targets=names)
+            ora.process(batch)
+            ref = ora.table()
+            ora.close()
+            oo = np.lexsort((ref["intron_end"], ref["intron_start"], ref["target"]))
+            for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand"):
+                assert np.array_equal(t[k].numpy().astype(np.int64), ref[k][oo].astype(np.int64)), (step, k)
+            assert np.array_equal(ijunc.cpu().numpy().astype(np.int64), ref["ijunc"][oo].astype(np.int64)), (step, "ijunc")
+            assert np.array_equal(t["counts"].numpy().astype(np.uint64), ref["counts"][oo]), (step, "counts")
+            starts = np.concatenate([[0], np.cumsum(ref["n_offsets"].astype(np.int64))])
+            flat = np.concatenate([ref["offsets"][starts[i]:starts[i + 1]] for i in oo])
+            got = np.repeat(t["hist_value"].numpy(), t["hist_count"].numpy())
+            assert np.array_equal(flat.astype(np.int64), got.astype(np.int64)), (step, "offsets")
+        assert slotted >= 3          # (the first step draws splitters: exact exchange; the others travel in slots)
+        ex.close()
+    finally:
+        dist.destroy_process_group()

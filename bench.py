@@ -454,14 +454,188 @@ def run_m1(args, local_rank):
                              "sample": "the oracle over the same 125 M alignments, one pass, %.1f s" % t_cpu}}
 
 
+def run_m(args, rank, world, local_rank):
+    """N > 1 (and --workload M): BASELINE.json's config 5.  Every rank holds its contiguous 12.5 chunks of the M stream
+    (intronprospector_amd/config5.py: 125 M alignments at full size) resident in HBM; a step = ipx_clear + its pushes
+    into ONE table + the record exchange over RCCL (all_to_all by key range) + ipx_finalize of the rank's key range +
+    the global sjN numbers.  The line carries what can be checked at this size -- conservation, sjN a permutation, key
+    ranges in order, one digest per range -- and `parity`: the SAME code over a down-scaled stream (at most 20 M
+    alignments in all), every rank's rows gathered and compared with the oracle's table."""
+    import torch
+    import torch.distributed as dist
+    import intronprospector_amd as ipa
+    from intronprospector_amd import config5, distributed, synth, _lib as L
+    from intronprospector_amd.distributed import RecordExchanger, SlotOverflow, table_to_torch, _all_gather_var
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    cpu_group = dist.new_group(backend="gloo")          # the checks after the timed region talk over CPU tensors
+
+    class Stream:
+        """one rank's share of a stream of the given chunk size (or explicit pieces), resident in HBM, and the step over it"""
+        def __init__(self, chunk_alignments, pieces=None, base=None):
+            t0 = time.perf_counter()
+            self.pieces = pieces if pieces is not None else config5.rank_pieces(rank, chunk_alignments)
+            self.base = base if base is not None else config5.rank_base(rank, chunk_alignments)
+            self.ups, self.sizes, self.host = [], [], []
+            for c, lo, hi in self.pieces:
+                b, self.names = config5.make_piece(c, lo, hi, chunk_alignments)
+                self.ups.append(upload(b, dev))
+                self.sizes.append((len(b["tid"]), len(b["cigar"])))
+                if chunk_alignments <= 1_000_000:
+                    self.host.append(b)              # (the small stream: rank 0's oracle wants every rank's pieces)
+            self.n = sum(a for a, _ in self.sizes)
+            self.n_words = sum(w for _, w in self.sizes)
+            self.generate_s = time.perf_counter() - t0
+            self.ex = ipa.JunctionsExtractor(targets=self.names, device=local_rank)
+            self.xch = RecordExchanger(dev, comm_device=comm_dev)
+            self.xch.strict = False
+            self.rescans = 0
+            self.n_items = 0
+
+        def scan(self):
+            self.ex.clear()
+            base = self.base
+            for (na, nw), (_, ptrs) in zip(self.sizes, self.ups):
+                self.ex.push_device(na, nw, ptrs, base_read_index=base)
+                base += na
+
+        def step(self):
+            self.scan()
+            self.n_items = self.ex.records_pending()
+            while True:
+                try:
+                    return self.xch.run(self.ex, self.n)
+                except SlotOverflow:                  # (sizes come from the batch before; a larger batch is scanned again)
+                    self.rescans += 1
+                    self.scan()
+
+        def timed(self, steps, warmup):
+            for _ in range(max(warmup, 2)):           # (the first step draws splitters: the exact exchange; slots from the second on)
+                self.step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = self.step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            elapsed = time.perf_counter() - t0
+            self.xch.check_last()
+            tmax = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=cpu_group)
+            return float(tmax.item()), out
+
+    chunk = args.chunk or 10_000_000
+    main_s = Stream(chunk)
+    elapsed, (table, ijunc) = main_s.timed(args.steps, args.warmup)
+    t = table_to_torch(main_s.ex, table, "cpu")
+    checks = config5.cross_rank_checks(t, ijunc.cpu(), int(table.n_records), group=cpu_group)
+    checks["slot_overflow_rescans"] = main_s.rescans
+    per_rank = {"alignments": main_s.n, "cigar_words": main_s.n_words, "records_after_combine": int(main_s.n_items),
+                "pushes": len(main_s.pieces), "generate_s": main_s.generate_s}
+    # kernel classes of one more step
+    main_s.ex.profile(True)
+    main_s.step()
+    torch.cuda.synchronize()
+    stats = main_s.ex.profile_read()
+    main_s.ex.profile(False)
+    main_s.ex.close()
+    del main_s.ups
+
+    # ---- parity: the same code over a down-scaled stream, all ranks' rows against the oracle's table
+    small_chunk = int(min(400_000, 20_000_000 // (12.5 * world))) // 2 * 2
+    sm = Stream(small_chunk)
+    for _ in range(3):                                 # (exact exchange, then twice in slots)
+        tab_s, ij_s = sm.step()
+    sm.xch.check_last()
+    ts = table_to_torch(sm.ex, tab_s, "cpu")
+    ts["ijunc"] = ij_s.cpu()
+    small_checks = config5.cross_rank_checks(ts, ij_s.cpu(), int(tab_s.n_records), group=cpu_group)
+    gathered = {k: torch.cat(_all_gather_var(ts[k], group=cpu_group)) for k in
+                ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc", "counts",
+                 "hist_value", "hist_count")}
+    all_host = [None] * world
+    dist.all_gather_object(all_host, sm.host, group=cpu_group)
+    parity = None
+    if rank == 0:
+        from tests.oracle_binding import Oracle
+        t0 = time.perf_counter()
+        ora = Oracle(targets=sm.names)
+        n_small = 0
+        for pieces in all_host:
+            for b in pieces:
+                ora.process(b)
+                n_small += len(b["tid"])
+        ref = ora.table()
+        ora.close()
+        oo = np.lexsort((ref["intron_end"], ref["intron_start"], ref["target"]))
+        bad = [k for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand", "ijunc")
+               if not np.array_equal(gathered[k].numpy().astype(np.int64), ref[k][oo].astype(np.int64))]
+        if not np.array_equal(gathered["counts"].numpy().astype(np.uint64), ref["counts"][oo]):
+            bad.append("counts")
+        starts = np.concatenate([[0], np.cumsum(ref["n_offsets"].astype(np.int64))])
+        flat = np.concatenate([ref["offsets"][starts[i]:starts[i + 1]] for i in oo]) if len(oo) else np.zeros(0, np.int64)
+        got = np.repeat(gathered["hist_value"].numpy(), gathered["hist_count"].numpy())
+        if not np.array_equal(flat.astype(np.int64), got.astype(np.int64)):
+            bad.append("offsets")
+        parity = {"equals_oracle": not bad, "differs_in": bad, "alignments": n_small, "junctions": int(len(oo)),
+                  "chunk_alignments": small_chunk, "oracle_s": time.perf_counter() - t0, "checks": small_checks}
+    sm.ex.close()
+    del sm
+
+    # ---- round 3's N > 1 line, kept as a sub-record: 10 M alignments per rank (seeds SEED_M0 + rank), one push per step
+    weak = None
+    if not args.no_configs:
+        ws = Stream(10_000_000, pieces=[(rank, 0, 10_000_000)], base=rank * 10_000_000)
+        w_el, _ = ws.timed(max(args.steps // 2, 3), 2)
+        weak = {"ms_per_step": w_el / max(args.steps // 2, 3) * 1e3, "alignments_per_gpu": ws.n,
+                "value": world * ws.n * max(args.steps // 2, 3) / w_el,
+                "workload": "S-sized: 10 M alignments per GPU (seed SEED_M0 + rank), one push, exchange, finalize"}
+        ws.ex.close()
+    dist.destroy_process_group()
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    n, nw, r = per_rank["alignments"], per_rank["cigar_words"], checks["records_made"] / world
+    b_alg = 20 + 4 * nw / n + 64 * r / n
+    out = {"metric": "alignments/sec junction extraction", "value": world * n * args.steps / elapsed, "unit": "alignments/s",
+           "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+           "config": {"workload": "M: BASELINE config 5 -- %d GPU(s) x 12.5 chunks of %d alignments (chunk i from seed %d + i) = %d "
+                                  "short reads in all, every rank's share pushed into one table, junction records exchanged by key "
+                                  "range over %s, %d junctions" % (world, chunk, synth.SEED_M0, world * n,
+                                                                  "RCCL" if args.backend == "nccl" else "gloo (rehearsal)",
+                                                                  checks["junctions"]),
+                      "alignments_per_gpu": n, "per_rank": per_rank, "multi": "exchange", "checks": checks, "parity": parity,
+                      "input": "SoA chunks resident in HBM before the timed region (decode and H2D excluded)"},
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": b_alg * n / (ms * 1e-3) / 1e9,
+                        "frac": b_alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "per GPU: the rank's algorithmic bytes (20 + 4c + 64j per alignment) / the step, exchange included",
+                        "kernels_ms_per_step": {k: v[1] for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])}}}
+    if weak is not None:
+        out["configs"] = {"weak_S": weak}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="S", choices=["S", "L", "G", "M1"],
-                    help="M1: ONE rank's share of BASELINE's config 5 (1 G short reads over 8 GPUs): 125 M alignments, "
-                         "chunks 0..12 of the M workload pushed into one table, whole table against the oracle")
+    ap.add_argument("--workload", default=None, choices=["S", "L", "G", "M1", "M"],
+                    help="default: S on one GPU, M on several.  M: BASELINE's config 5 (1 G short reads over 8 GPUs): every rank "
+                         "its contiguous 12.5 chunks of 10 M alignments in one table, record exchange over RCCL.  M1: ONE rank's "
+                         "share of it without an exchange, the whole table against the oracle")
+    ap.add_argument("--chunk", type=int, default=0, help="workload M: alignments per chunk (default 10 M; smaller: rehearsals)")
     ap.add_argument("--reads", type=int, default=0, help="alignments per GPU (default: 10 M for S and G, 2 M for L)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -493,7 +667,14 @@ def main():
 
     import torch            # before the package: libipx.so must bind to the HIP runtime torch brings along
     from intronprospector_amd import synth
-    kind = args.workload
+    kind = args.workload or ("M" if world > 1 else "S")
+    if kind == "M":
+        out = run_m(args, rank, world, local_rank)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
     if kind == "M1":
         out = run_m1(args, local_rank)
         sys.stdout.flush()

@@ -162,8 +162,17 @@ int ipx_group_create(const ipx_params *params, uint32_t n_devices, const int32_t
         for (uint32_t i = 0; i < n_devices; ++i)
             for (uint32_t k = 0; k < n_devices; ++k) {
                 if (g->m[i].device == g->m[k].device) continue;
-                (void)hipSetDevice(g->m[i].device);
-                (void)hipDeviceEnablePeerAccess(g->m[k].device, 0);      // "already enabled" is fine
+                // members on different devices without RCCL exchange by peer copies: the devices must see each other
+                // ("already enabled" is fine; anything else is not -- round 3 threw the answer away, and a pair of GPUs
+                // without peer access would have failed at the first exchange, or copied through the host)
+                int can = 0;
+                if (hipSetDevice(g->m[i].device) != hipSuccess ||
+                    hipDeviceCanAccessPeer(&can, g->m[i].device, g->m[k].device) != hipSuccess || !can) {
+                    rc = IPX_EDEVICE;
+                    continue;
+                }
+                const hipError_t pe = hipDeviceEnablePeerAccess(g->m[k].device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) rc = IPX_EDEVICE;
                 (void)hipGetLastError();
             }
     }

@@ -187,3 +187,70 @@ def test_shard_merge_world_8(oracle_lib):
     ok, msg, n = run_workers(_worker, 8, (_free_port(), False), timeout=600)
     assert ok, "merged table differs from the single run in: %s" % msg
     assert n > 100
+
+
+def _config5_worker(rank, world, port, q):
+    """BASELINE config 5's harness on CPU: the shares of the stream, and the cross-rank checks of the bench line over
+    key-range halves of an oracle table (what the exchange path leaves on two ranks)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from intronprospector_amd import config5, synth
+        chunk = 4000
+        pieces = config5.rank_pieces(rank, chunk)
+        batches = [config5.make_piece(c, lo, hi, chunk) for c, lo, hi in pieces]
+        names = batches[0][1]
+        n_local = sum(len(b["tid"]) for b, _ in batches)
+        assert n_local == config5.share_alignments(chunk) == 50_000 and config5.rank_base(rank, chunk) == rank * 50_000
+        # every rank can build the whole small stream (here: both shares) and its oracle table
+        whole = []
+        for r in range(world):
+            whole += [config5.make_piece(c, lo, hi, chunk)[0] for c, lo, hi in config5.rank_pieces(r, chunk)]
+        ref = _oracle_table(synth.concat_batches(whole), names, {}, None)
+        oo = np.lexsort((ref["intron_end"], ref["intron_start"], ref["target"]))
+        J = len(oo)
+        cut = [0, J // 2, J][rank:rank + 2] if world == 2 else [J * rank // world, J * (rank + 1) // world]
+        rows = oo[cut[0]:cut[1]]
+        i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int64))
+        starts = np.concatenate([[0], np.cumsum(ref["n_offsets"].astype(np.int64))])
+        hv, hc = [], []
+        for i in rows:
+            v, c = np.unique(ref["offsets"][starts[i]:starts[i + 1]], return_counts=True)
+            hv.append(v); hc.append(c)
+        t = {k: i64(ref[k][rows]) for k in ("target", "intron_start", "intron_end", "anchor_start", "anchor_end", "strand")}
+        t["counts"] = i64(ref["counts"][rows])
+        t["hist_value"] = i64(np.concatenate(hv) if hv else np.zeros(0))
+        t["hist_count"] = i64(np.concatenate(hc) if hc else np.zeros(0))
+        ijunc = i64(ref["ijunc"][rows])
+        n_raw = int(ref["counts"].sum()) if rank == 0 else 0         # (the scans' record count, wherever it was made)
+        good = config5.cross_rank_checks(t, ijunc, n_raw)
+        # ... and what they say when something is wrong: a junction numbered twice, a range out of place, a read lost
+        bad_ij = ijunc.clone()
+        if rank == 0 and len(bad_ij) > 1:
+            bad_ij[0] = bad_ij[1]
+        twice = config5.cross_rank_checks(t, bad_ij, n_raw)
+        lost = config5.cross_rank_checks(t, ijunc, n_raw + (1 if rank == 0 else 0))
+        t2 = dict(t)
+        if rank == 1 and len(rows):
+            t2["target"] = t["target"].clone()
+            t2["target"][0] = 0
+            t2["intron_start"] = t["intron_start"].clone()
+            t2["intron_start"][0] = 0
+        moved = config5.cross_rank_checks(t2, ijunc, n_raw)
+        if rank == 0:
+            q.put((good, twice["ijunc_is_a_permutation"], lost["conservation"], moved["key_ranges_in_order"], J,
+                   [p for p in pieces], config5.rank_pieces(1, chunk)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_shares_and_cross_rank_checks(oracle_lib):
+    from tests.mp_util import run_workers
+    good, twice_ok, lost_ok, moved_ok, J, p0, p1 = run_workers(_config5_worker, 2, (_free_port(),), timeout=240)
+    assert good["ijunc_is_a_permutation"] and good["conservation"] and good["key_ranges_in_order"]
+    assert good["junctions"] == J and len(good["range_digests"]) == 2 and good["range_digests"][0] != good["range_digests"][1]
+    assert not twice_ok and not lost_ok and not moved_ok
+    # rank 0: chunks 0..11 whole and the first half of 12; rank 1: the second half of 12, then 13..24
+    assert p0[0] == (0, 0, 4000) and p0[-1] == (12, 0, 2000) and len(p0) == 13
+    assert p1[0] == (12, 2000, 4000) and p1[-1] == (24, 0, 4000) and len(p1) == 13

@@ -250,3 +250,28 @@ def test_rccl_exchange_with_a_different_batch_every_step():
         ex.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_config5_line_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 line (BASELINE config 5: every rank its 12.5 chunks in one table, record exchange, finalize, global
+    sjN) on two ranks that share the GPU, collectives over gloo, a stream of small chunks: the line must carry the
+    cross-rank checks and an oracle parity record, all good."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--chunk", "60000", "--no-configs"]
+    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["alignments_per_gpu"] == 750_000
+    assert d["config"]["workload"].startswith("M: BASELINE config 5")
+    ck = d["config"]["checks"]
+    assert ck["conservation"] and ck["ijunc_is_a_permutation"] and ck["key_ranges_in_order"] and len(ck["range_digests"]) == 2
+    par = d["config"]["parity"]
+    assert par["equals_oracle"] and par["alignments"] == 2 * 25 * (par["chunk_alignments"] // 2) and par["junctions"] > 1000
+    assert par["checks"]["conservation"] and par["checks"]["ijunc_is_a_permutation"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

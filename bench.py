@@ -139,6 +139,11 @@ def cpu_baseline(batch, names, kind, budget_reads, budget_s=10.0, all_cores=True
         passes += 1
     info = host_info()
     out = {"value": n * passes / spent, "unit": "alignments/s", "cores": 1, "kind": "port",
+           # the survey's probe of the REFERENCE itself (unmodified sources behind a throw-away SAM shim,
+           # 2 M synthetic 100 bp reads, one thread, another machine): the port keeps junctions in a hash table where the
+           # reference has a std::map with std::string compares -- `value` is the port's, not the reference's
+           "reference_probe": {"value": 0.65e6, "unit": "alignments/s", "cores": 1,
+                               "source": "BASELINE.md section 2 / SURVEY.md section 6 (indicative, measured once in the survey's container)"},
            "sample": "%d passes over %s %d alignments of the %s workload, oracle/libipxo.so (scalar C restatement), "
                      "%d junctions, %.1f s of CPU work" % (passes, "all" if n == len(batch["tid"]) else "the first",
                                                            n, kind, nj, spent)}
@@ -273,6 +278,7 @@ def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, 
     dev_ms = sum(v[1] for v in stats.values()) / breakdown_steps if stats else None
     tr = load_traffic(kind)
     traffic_step = tr.get("step_bytes")
+    traffic_lower = tr.get("step_bytes_lower")
     out = {
         "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "basis": "whole step: SURVEY 8(d) algorithmic bytes (20 + 4c + 64j per alignment) / timed step",
@@ -282,6 +288,10 @@ def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, 
         "bytes_per_alignment": b_alg, "algorithmic_bytes_per_step": alg_step,
         "traffic_step_bytes": traffic_step,
         "waste_ratio": (traffic_step / alg_step) if traffic_step else None,
+        # FETCH_SIZE is doubled only for the classes whose loads are 16-byte-per-lane streams; the others are a range
+        # (profiles/pmc_traffic.py): `traffic` is its upper end, this the lower
+        "traffic_lower": traffic_lower,
+        "waste_ratio_lower": (traffic_lower / alg_step) if traffic_lower else None,
         "launches_per_step": tr.get("launches_per_step"),
         "traffic_source": ("profiles/traffic.json is stale (measured on kernel sources %s, these are %s): traffic not reported"
                            % (tr.get("measured_on"), kernel_source_hash())) if tr.get("stale") else

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """HBM-side traffic per kernel class and per step from two rocprofv3 counter runs (FETCH_SIZE, WRITE_SIZE; they
 cannot share a run), as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts wide
-(16 B per lane) streaming reads at half their bytes -> doubled; WRITE_SIZE as is.  Both are L2 <-> fabric
-requests: Infinity-Cache hits are included, so for working sets below 256 MiB this is an upper bound of HBM traffic.
+(16 B per lane) streaming reads at half their bytes -> doubled; WRITE_SIZE as is.  The doubling is for THAT access
+pattern only (round 4, the review's item 7): classes whose loads are 16-byte-per-lane streams (STREAMING below) are
+doubled; for the others -- k_scan_short's 1-4-byte field loads, k_reduce's payload gathers, the splitter look-ups of
+k_bs_assign -- nobody knows the factor, so they are reported as a RANGE: lower = FETCH_SIZE + WRITE_SIZE, upper =
+2 x FETCH_SIZE + WRITE_SIZE.  step_bytes (what bench.py prints as roofline.traffic) is the upper end, step_bytes_lower
+the lower.  Both counters are L2 <-> fabric requests: Infinity-Cache hits are included, so for working sets below
+256 MiB even the lower end bounds HBM traffic from above.
 
 usage: pmc_traffic.py WORKLOAD STEPS fetch_dir write_dir [traffic.json]
   STEPS = steps the profiled bench.py ran in all (warm-up + 1 probe + timed + 3 breakdown)
@@ -24,6 +29,12 @@ CLASS = [
     (r"k_scan_sums|k_scan_top|k_scan_apply|k_scan_small", "scan_u32"),
     (r"k_emit_|k_finish_|k_motif|k_bins|k_rank_|k_publish|k_set_counters|fillBuffer|copyBuffer", "small"),
 ]
+
+
+# classes whose global loads are 16 bytes per lane, streaming (the guide's case): k_scatter / k_bs_leaf / k_count_heads read
+# items, k_hist reads sixteen digit bytes per lane, the scans of long CIGARs refill their rings in 16-byte loads
+STREAMING = {"k_scatter", "k_hist", "k_bs_leaf", "k_count_heads", "k_bs_bounds"}
+STREAMING_BY_WORKLOAD = {"L": {"k_scan"}}
 
 
 def klass(name):
@@ -52,19 +63,24 @@ def main():
     wl, steps, fdir, wdir = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
     path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
     fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
-    out, step_bytes, launches = {}, 0.0, 0
+    out, step_bytes, step_lower, launches = {}, 0.0, 0.0, 0
     detail = {}
+    streaming = STREAMING | STREAMING_BY_WORKLOAD.get(wl, set())
     for c in sorted(set(fetch) | set(write)):
         fkb, fn = fetch.get(c, [0.0, 0])
         wkb, wn = write.get(c, [0.0, 0])
         n = max(fn, wn, 1)
-        total = fkb * 1024 * 2 + wkb * 1024          # FETCH_SIZE doubled (gfx950), both in KB
-        out[c] = total / steps
+        upper = fkb * 1024 * 2 + wkb * 1024          # FETCH_SIZE doubled (gfx950), both in KB
+        lower = upper if c in streaming else fkb * 1024 + wkb * 1024
+        out[c] = upper / steps
         detail[c] = {"launches_per_step": n / steps, "fetch_kb_per_launch": fkb / n, "write_kb_per_launch": wkb / n,
-                     "bytes_per_step": total / steps}
-        step_bytes += total / steps
+                     "bytes_per_step": upper / steps, "bytes_per_step_lower": lower / steps,
+                     "loads": "16 B per lane, streaming (FETCH_SIZE doubled)" if c in streaming else "mixed (a range)"}
+        step_bytes += upper / steps
+        step_lower += lower / steps
         launches += n
     out["step_bytes"] = step_bytes
+    out["step_bytes_lower"] = step_lower
     out["launches_per_step"] = launches / steps
     try:
         t = json.load(open(path))
@@ -81,9 +97,11 @@ def main():
     t["kernel_sources_sha16"] = stamp
     t[wl] = out
     t.setdefault("detail", {})[wl] = detail
-    t["note"] = ("bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; FETCH doubled per MI355X_MICROARCH.md, gfx950), L2 <-> fabric "
-                 "including Infinity-Cache hits; per STEP by kernel class (k_scan = scan kernels + their second stage + stripe closing), "
-                 "step_bytes = all launches of a step")
+    t["note"] = ("per class: bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; FETCH doubled per MI355X_MICROARCH.md, gfx950, which holds "
+                 "for 16-byte-per-lane streaming loads: detail.<class>.loads says which classes those are; for the others "
+                 "bytes_per_step_lower = FETCH_SIZE + WRITE_SIZE is the other end of the range); L2 <-> fabric including Infinity-Cache "
+                 "hits; per STEP by kernel class (k_scan = scan kernels + their second stage + stripe closing); step_bytes / "
+                 "step_bytes_lower = all launches of a step, upper / lower end")
     json.dump(t, open(path, "w"), indent=1)
     print(json.dumps({wl: out}, indent=1))
 

@@ -167,6 +167,10 @@ __device__ __forceinline__ uint4 bs_restore(uint4 it, const BsSorted &bs) {
 //  * two barriers per pass: after the counts every wave scans all 256 digit totals ITSELF (four digits per lane,
 //    one DPP scan) and writes only its own row of bases, which only it reads; the second barrier stands between
 //    placing the items in the tile and taking them back.
+// BARRIERS (round-4 audit): `n` is the caller's block-uniform leaf size.  The early return `if (n <= 1 || no varying bit)`
+// tests n and vs[], which every thread reads from sh.vary[] after the barrier that follows its last write; the pass loop
+// `if (!((active >> k) & 1u)) continue` tests `active`, computed by every thread from the same vs[] (readfirstlane'd); the
+// two barriers per pass are unconditional inside the loop body.
 template <uint32_t IPT>
 __device__ __forceinline__ BsSorted bs_block_sort(BsShared<IPT> &sh, uint4 (&it)[IPT], uint32_t n BS_ST_ARGS) {
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -600,6 +604,9 @@ __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, co
             sh.rng[1] = e;
         }
         __syncthreads();
+        // (uniform: sh.rng[] was written by thread 0 before the barrier above and is written again only after the barrier
+        // that closes the leaf -- the one below, or the one at the loop's end; n_min, CAP: arguments / constants.  Every
+        // branch of the leaf -- skip, sort, too-large -- ends with exactly one barrier before the next leaf's bounds)
         const uint32_t s = sh.rng[0], n = sh.rng[1] - s;
         if (s == BS_SENT || n <= n_min || (n > CAP && CAP < BS_CAP)) {       // nothing here, or the other launch's leaf
             __syncthreads();

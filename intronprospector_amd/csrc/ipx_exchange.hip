@@ -79,6 +79,8 @@ __global__ __launch_bounds__(1024) void k_part_plan(unsigned long long *__restri
     __shared__ unsigned long long wave_sum[16];
     __shared__ unsigned long long part_total[MAX_PARTS];
     const uint32_t b = threadIdx.x, lane = b & 63u, wave = b >> 6;
+    // (barriers, round-4 audit: both sit in the body of a loop over p < n_parts, a kernel argument: every thread makes
+    // every turn; `b < n_blocks` guards loads and stores only.  The same in k_part_plan_slots below.)
     for (uint32_t p = 0; p < n_parts; ++p) {
         const unsigned long long v = b < n_blocks ? blk[(uint64_t)b * MAX_PARTS + p] : 0ull;
         unsigned long long incl = v;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void k_adopt_slots(const uint4 *__restrict__ r
         if (c > room) c = room;
         if (q < slot) base += c; else count = c;
     }
-    if (blockIdx.x == 0 && slot == 0) {
+    if (blockIdx.x == 0 && slot == 0) {              // (the barrier inside: blockIdx only -- the whole block or none of it)
         // what every rank receives in all (the counts rows of all senders): the same numbers on every rank
         if (threadIdx.x < MAX_PARTS) {
             unsigned long long tot = 0;

@@ -174,6 +174,9 @@ __global__ __launch_bounds__(256) void k_init_rows(uint32_t n_j, uint32_t n_b, u
     for (uint64_t b = t0; b < n_b; b += stride) bin_count[b] = 0;
 }
 
+// (Barriers, round-4 audit: k_reduce, k_count_heads, k_write_heads have none -- a wave works its chunk alone, and the
+// early `return` of a wave whose chunk lies beyond the items leaves no barrier behind.  The two block barriers of this file,
+// in k_finish_junctions and k_rank_* further down, are unconditional: the grid-stride loops before them hold none.)
 // ---- wave-segmented reductions -------------------------------------------------
 // seg ids are non-decreasing over the lanes; the result is valid at head lanes.
 __device__ __forceinline__ uint32_t seg_last_lane(uint64_t heads, uint32_t lane) {

@@ -1194,6 +1194,14 @@ __device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
 #define IPX_ST_LAP(k)
 #endif
 
+// BARRIERS (audited in round 4, after the divergent barrier of rounds 2-3: see "Everybody has read the count" below).
+// Every __syncthreads() of this kernel that sits under a condition carries a note "(uniform: ...)" naming why all threads
+// of the block evaluate that condition alike.  The rule they all follow: a condition that guards a barrier is computed
+// only from (a) kernel arguments and blockIdx, (b) loop counters that every thread steps alike, (c) a shared-memory word
+// that was last written BEFORE a barrier which every thread has passed, and is not written again until every thread has
+// passed a LATER barrier -- i.e. there is a barrier between the last write and the read, and one between the read and
+// the next write.  (c) is the one that was violated: pool_n was read for the early-combine test while faster threads
+// already added the next round's records to it.
 template <uint32_t RPT, uint32_t POOL, uint32_t BT>
 __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                                     const int32_t *__restrict__ a_tid,
@@ -1249,6 +1257,9 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     unsigned long long my_err = IPX_ERRW_NONE;
     if (t == 0) dx_n = 0;
     __syncthreads();
+    // (barriers inside: `total`, `final_pass`, `recombine` are the caller's block-uniform values -- see the call sites --,
+    // and the branches that hold barriers test nothing else: `if (recombine)`, `if (!final_pass)`; the per-round
+    // `if (r * BT >= total) continue` skips no barrier)
     auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
         for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
         __syncthreads();
@@ -1408,7 +1419,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             }
             fold_and_insert(k, it, cat, ord, lo, hi, cw, live);
         }
-        if (recombine) {
+        if (recombine) {                                   // (uniform: the caller's argument)
             __syncthreads();                               // every count word of the pool is zero now
 #pragma unroll
             for (uint32_t r = 0; r < CR; ++r) {
@@ -1484,7 +1495,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 
     // the tile's records -> record arrays (total <= POOL)
     auto store_pool = [&](const uint32_t total, const uint32_t comb, const bool recombined) {
-        if (!comb) {
+        if (!comb) {                                       // (uniform: a kernel argument masked with the tile number)
             if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;
@@ -1641,7 +1652,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             // A tile of mostly two-junction reads emits more than the pool holds (S: 3 % of the tiles, a quarter of
             // all records that left the scan uncombined through the second stage).  If the first half of the tile
             // filled more than its share, fold what is there and go on in the room that makes.
-            if (r + 1 < RPT && comb) {
+            if (r + 1 < RPT && comb) {                     // (uniform: r is the unrolled round, comb see store_pool)
                 __syncthreads();
                 const uint32_t filled = pool_n;
                 // Everybody has read the count before anybody goes on adding to it.  Without this barrier (rounds 2 and
@@ -1650,6 +1661,8 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 // block went into combine_pool -- and its barriers -- while the rest did not: one finalize in eight of
                 // the M shard lost or garbled a tile's records.
                 __syncthreads();
+                // (uniform: `filled` is pool_n, last added to before the first of the two barriers above and not again
+                // until every thread has passed the second)
                 if (2u * filled + 64u > POOL && filled <= POOL) {
                     combine_pool(filled, false, false);
                     recombined = true;
@@ -1664,6 +1677,9 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         for (;;) {
             __syncthreads();
             if (from_walk) IPX_ST_LAP(2); else IPX_ST_LAP(1);
+            // (uniform: pool_n was last added to before the barrier at the top of this loop -- phase 1's records, an early
+            // combine's result, or a walk pass's -- and is next written by thread 0 after the barrier that follows the store,
+            // at the start of a walk pass or of the next tile; `recombined` is set under the uniform early-combine test)
             const uint32_t total = pool_n;
             if (total <= POOL) {
                 store_pool(total, comb, recombined);
@@ -1708,6 +1724,9 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             }
             __syncthreads();
             IPX_ST_LAP(3);                      // combine + reservation + copy-out
+            // (uniform: dx_n was last added to in phase 1, before the barrier at the top of this loop, or set by thread 0
+            // between the two barriers below; it is read here after a barrier and not written again before the next one.
+            // last_tile: blockIdx, gridDim and the tile counter)
             const uint32_t have = dx_n;
             if (!(have >= BT || (last_tile && have != 0u))) break;
             const uint32_t take = have < BT ? have : BT, from = have - take;
@@ -1717,7 +1736,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             __syncthreads();
             if (t == 0) { pool_n = 0; dx_n = from; }
             __syncthreads();
-                if (wave * 64u < take) {
+                if (wave * 64u < take) {       // (wave-uniform, and no block barrier inside: a wave without alignments to walk skips to the loop's top)
                     const bool mine = t < take;
                     const uint64_t i = mine ? dx_list[from + t] : 0u;
                     ReadCtx c;

@@ -506,27 +506,52 @@ def run_m(args, rank, world, local_rank):
             self.n_words = sum(w for _, w in self.sizes)
             self.generate_s = time.perf_counter() - t0
             self.ex = ipa.JunctionsExtractor(targets=self.names, device=local_rank)
+            # (two handles that take turns: the scan of step k + 1 runs on a helper thread under the exchange of step k)
+            self.ex2 = None if args.no_overlap else ipa.JunctionsExtractor(targets=self.names, device=local_rank)
+            self.ahead = None
+            self.cur = self.ex
             self.xch = RecordExchanger(dev, comm_device=comm_dev)
             self.xch.strict = False
             self.rescans = 0
             self.n_items = 0
 
-        def scan(self):
-            self.ex.clear()
+        def scan(self, h):
+            h.clear()
             base = self.base
             for (na, nw), (_, ptrs) in zip(self.sizes, self.ups):
-                self.ex.push_device(na, nw, ptrs, base_read_index=base)
+                h.push_device(na, nw, ptrs, base_read_index=base)
                 base += na
 
         def step(self):
-            self.scan()
-            self.n_items = self.ex.records_pending()
+            import threading
+            if self.ex2 is None:
+                self.scan(self.ex)
+            else:
+                if self.ahead is None:
+                    self.scan(self.ex)
+                    self.cur = self.ex
+                else:
+                    self.cur, th = self.ahead
+                    th.join()
+                nxt = self.ex2 if self.cur is self.ex else self.ex
+                th = threading.Thread(target=self.scan, args=(nxt,))
+                th.start()
+                self.ahead = (nxt, th)
+            self.n_items = self.cur.records_pending()
             while True:
                 try:
-                    return self.xch.run(self.ex, self.n)
+                    return self.xch.run(self.cur, self.n)
                 except SlotOverflow:                  # (sizes come from the batch before; a larger batch is scanned again)
                     self.rescans += 1
-                    self.scan()
+                    self.scan(self.cur)
+
+        def close(self):
+            if self.ahead is not None:
+                self.ahead[1].join()
+                self.ahead = None
+            self.ex.close()
+            if self.ex2 is not None:
+                self.ex2.close()
 
         def timed(self, steps, warmup):
             for _ in range(max(warmup, 2)):           # (the first step draws splitters: the exact exchange; slots from the second on)
@@ -547,18 +572,28 @@ def run_m(args, rank, world, local_rank):
     chunk = args.chunk or 10_000_000
     main_s = Stream(chunk)
     elapsed, (table, ijunc) = main_s.timed(args.steps, args.warmup)
-    t = table_to_torch(main_s.ex, table, "cpu")
+    t = table_to_torch(main_s.cur, table, "cpu")
     checks = config5.cross_rank_checks(t, ijunc.cpu(), int(table.n_records), group=cpu_group)
     checks["slot_overflow_rescans"] = main_s.rescans
     per_rank = {"alignments": main_s.n, "cigar_words": main_s.n_words, "records_after_combine": int(main_s.n_items),
                 "pushes": len(main_s.pieces), "generate_s": main_s.generate_s}
-    # kernel classes of one more step
-    main_s.ex.profile(True)
+    # kernel classes of one more step (of the handle whose turn it is)
+    if main_s.ahead is not None:
+        main_s.ahead[1].join()
+    prof_h = main_s.ahead[0] if main_s.ahead is not None else main_s.ex
+    other_h = main_s.cur if main_s.ahead is not None else None
+    if other_h is not None:
+        other_h.profile(True)                      # (its scan of the step after runs under this step's exchange)
+    prof_h.profile(True)
     main_s.step()
+    if main_s.ahead is not None:
+        main_s.ahead[1].join()
     torch.cuda.synchronize()
-    stats = main_s.ex.profile_read()
-    main_s.ex.profile(False)
-    main_s.ex.close()
+    stats = prof_h.profile_read()
+    if other_h is not None:
+        for k, v in other_h.profile_read().items():
+            stats[k] = (stats[k][0] + v[0], stats[k][1] + v[1]) if k in stats else v
+    main_s.close()
     del main_s.ups
 
     # ---- parity: the same code over a down-scaled stream, all ranks' rows against the oracle's table
@@ -567,7 +602,7 @@ def run_m(args, rank, world, local_rank):
     for _ in range(3):                                 # (exact exchange, then twice in slots)
         tab_s, ij_s = sm.step()
     sm.xch.check_last()
-    ts = table_to_torch(sm.ex, tab_s, "cpu")
+    ts = table_to_torch(sm.cur, tab_s, "cpu")
     ts["ijunc"] = ij_s.cpu()
     small_checks = config5.cross_rank_checks(ts, ij_s.cpu(), int(tab_s.n_records), group=cpu_group)
     gathered = {k: torch.cat(_all_gather_var(ts[k], group=cpu_group)) for k in
@@ -599,7 +634,7 @@ def run_m(args, rank, world, local_rank):
             bad.append("offsets")
         parity = {"equals_oracle": not bad, "differs_in": bad, "alignments": n_small, "junctions": int(len(oo)),
                   "chunk_alignments": small_chunk, "oracle_s": time.perf_counter() - t0, "checks": small_checks}
-    sm.ex.close()
+    sm.close()
     del sm
 
     # ---- round 3's N > 1 line, kept as a sub-record: 10 M alignments per rank (seeds SEED_M0 + rank), one push per step
@@ -610,7 +645,7 @@ def run_m(args, rank, world, local_rank):
         weak = {"ms_per_step": w_el / max(args.steps // 2, 3) * 1e3, "alignments_per_gpu": ws.n,
                 "value": world * ws.n * max(args.steps // 2, 3) / w_el,
                 "workload": "S-sized: 10 M alignments per GPU (seed SEED_M0 + rank), one push, exchange, finalize"}
-        ws.ex.close()
+        ws.close()
     dist.destroy_process_group()
     if rank != 0:
         return None
@@ -626,6 +661,8 @@ def run_m(args, rank, world, local_rank):
                                                                   "RCCL" if args.backend == "nccl" else "gloo (rehearsal)",
                                                                   checks["junctions"]),
                       "alignments_per_gpu": n, "per_rank": per_rank, "multi": "exchange", "checks": checks, "parity": parity,
+                      "overlap": (None if args.no_overlap else "the scan of step k + 1 (second handle, helper thread) runs under the "
+                                  "exchange and reduce of step k"),
                       "input": "SoA chunks resident in HBM before the timed region (decode and H2D excluded)"},
            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": b_alg * n / (ms * 1e-3) / 1e9,
                         "frac": b_alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -659,6 +696,8 @@ def main():
                     help="N>1: exchange junction records by key range (default) or merge shard tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a one-GPU box (tables merged on the CPU)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1 / rehearsal: one handle, scan and exchange one after the other (round 3's step)")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="N=1 only: run the N>1 code path (process group of one rank) to exercise the RCCL calls")
     args = ap.parse_args()
@@ -747,21 +786,47 @@ def main():
     n_records = [0]
     n_merged = [0]
     n_items = [0]
+    # The exchange path runs on TWO handles that take turns (round 4): while the records of batch k travel, are adopted and
+    # reduced on handle A -- a chain of small kernels, a collective and three read-backs on the exchanger's stream --,
+    # a helper thread scans batch k + 1 on handle B's own stream.  (ctypes releases the interpreter lock during a call;
+    # different handles are independent, include/ipx.h.)  --no-overlap: one handle, one thing after the other, as in round 3.
+    overlap = exchanger is not None and not args.no_overlap
+    ex2 = None
+    scanned = [None]          # the handle whose scan of the NEXT batch is under way (or done), and the thread doing it
+    if overlap:
+        ex2 = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
+        ex2.reserve(0, 0, n_words // 2 + 1024)
+
+    def scan(h):
+        h.clear()
+        h.push_device(n, n_words, ptrs, base_read_index=rank * n)
 
     def step():
-        ex.clear()
-        ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
-        n_items[0] = ex.records_pending()
+        import threading
+        if overlap:
+            if scanned[0] is None:                # the first step scans its own batch
+                scan(ex)
+                cur = ex
+            else:
+                cur, th = scanned[0]
+                th.join()
+            nxt = ex2 if cur is ex else ex
+            th = threading.Thread(target=scan, args=(nxt,))
+            th.start()
+            scanned[0] = (nxt, th)
+        else:
+            cur = ex
+            scan(cur)
+        n_items[0] = cur.records_pending()
         if exchanger is not None:
             # junction records -> key-range owners over RCCL (all_to_all), then the local finalize
             from intronprospector_amd.distributed import SlotOverflow
             while True:
                 try:
-                    table, ijunc = exchanger.run(ex, n)
+                    table, ijunc = exchanger.run(cur, n)
                     break
                 except SlotOverflow:              # (sizes come from the batch before; a larger batch is scanned again)
-                    ex.clear()
-                    ex.push_device(n, n_words, ptrs, base_read_index=rank * n)
+                    scan(cur)
             n_records[0] = table.n_records
             n_merged[0] = int(table.n_junctions)          # this rank's key range; summed after the timed loop
             return table
@@ -780,16 +845,28 @@ def main():
     # A probe step with event pairs around every launch tells which kernel class dominates.  The timed region
     # then brackets the launches of that class alone (an event before and after each): pairs around all
     # launches of a step cost a 10 M-alignment step about 10 % of its time.
+    def both(f):                  # (the exchange path alternates between two handles: their kernel timers are read together)
+        a = f(ex)
+        if ex2 is not None:
+            b = f(ex2)
+            if isinstance(a, dict):
+                for k, v in b.items():
+                    a[k] = (a[k][0] + v[0], a[k][1] + v[1]) if k in a else v
+        return a
     for _ in range(args.warmup):
         table = step()
-    ex.profile(True)              # one more untimed step, all launches bracketed (the first steps also allocate)
+    both(lambda h: h.profile(True))   # one more untimed step, all launches bracketed (the first steps also allocate)
     table = step()
+    if ex2 is not None:
+        table = step()
     torch.cuda.synchronize()
-    warm = ex.profile_read()
+    warm = both(lambda h: h.profile_read())
+    if ex2 is not None:
+        warm = {k: (v[0], v[1] / 2) for k, v in warm.items()}
     bracketed = {"k_scan", "k_scatter", "k_reduce"}
     cand = {k: v for k, v in warm.items() if k in bracketed}
     dominant = max(cand.items(), key=lambda kv: kv[1][1])[0] if cand else ("k_scan" if kind == "L" else "k_scatter")
-    ex.profile_only(dominant)
+    both(lambda h: h.profile_only(dominant))
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -802,15 +879,17 @@ def main():
     elapsed = time.perf_counter() - t0
     if exchanger is not None:
         exchanger.check_last()
-    timed = ex.profile_read()
+    timed = both(lambda h: h.profile_read())
     # per-kernel breakdown: a few more steps, untimed, with event pairs around every launch
-    breakdown_steps = 3
-    ex.profile(True)
+    breakdown_steps = 4 if ex2 is not None else 3
+    both(lambda h: h.profile(True))
     for _ in range(breakdown_steps):
         table = step()
+    if scanned[0] is not None:
+        scanned[0][1].join()
     torch.cuda.synchronize()
-    stats = ex.profile_read()
-    ex.profile(False)
+    stats = both(lambda h: h.profile_read())
+    both(lambda h: h.profile(False))
     if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -823,6 +902,8 @@ def main():
     n_junctions = n_merged[0] if multi else int(table.n_junctions)
     r = int(n_records[0])
     ex.close()
+    if ex2 is not None:
+        ex2.close()
 
     out = None
     if rank == 0:
@@ -845,7 +926,9 @@ def main():
                        "alignments_per_gpu": n, "cigar_words": n_words, "records": r, "junctions": n_junctions,
                        "input": "SoA batch resident in HBM before the timed region (decode and H2D excluded)",
                        "order": "shuffled" if args.shuffle else "coordinate-sorted", "seed": seed, "generate_s": t_gen,
-                       "multi": (args.multi if multi else None)},
+                       "multi": (args.multi if multi else None),
+                       "overlap": ("the scan of batch k + 1 (second handle, helper thread) runs under the exchange and reduce of "
+                                   "batch k" if overlap else None)},
             "roofline": roofline,
         }
         if cpu is not None:

@@ -1600,7 +1600,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     const uint64_t t_pb = 0, t_pe = al(t_pb + 8 * nb), t_oo = al(t_pe + 8 * nb), t_is = al(t_oo + 8 * (nb + 1)), t_crc = al(t_is + 4 * nb),
                    t_st = al(t_crc + 4 * nb), t_cnt = al(t_st + 4 * nb), t_pre = al(t_cnt + 4 * (nb + 1)), t_sb = al(t_pre + 4 * (nb + 1)),
                    t_sf = al(t_sb + 8 * (nb + 1)), t_sums = al(t_sf + 8 * (nb + 1)), t_flags = al(t_sums + 4 * (ipx_div_up(nb, 4096) + 8)),
-                   t_map = al(t_flags + 64), t_total = al(t_map + 4ull * f->n_tid_map);
+                   t_map = al(t_flags + 64), t_ord = al(t_map + 4ull * f->n_tid_map), t_total = al(t_ord + 4 * nb);
     // Does it fit?  The file's bytes, the inflated stream, the decoded batch (20 bytes per alignment and the CIGAR words:
     // at most half of the stream again) and the tables all lie on the device at once.  Asked BEFORE anything is copied: a
     // caller that hears IPX_ENOMEM reads the file through its ordinary batches.
@@ -1646,11 +1646,19 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     HIPCHK(hipMemcpyAsync(tb + t_is, f->isize, 4 * nb, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(tb + t_crc, f->crc32, 4 * nb, hipMemcpyHostToDevice, s));
     if (f->n_tid_map) HIPCHK(hipMemcpyAsync(tb + t_map, f->tid_map, 4ull * f->n_tid_map, hipMemcpyHostToDevice, s));
+    // the blocks longest first (by their compressed size): the lanes of a wave then take blocks of about one length and
+    // the waves that start last are the short ones
+    std::vector<uint32_t> order(nb);
+    for (uint64_t b = 0; b < nb; ++b) order[b] = (uint32_t)b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return f->payload_end[x] - f->payload_begin[x] > f->payload_end[y] - f->payload_begin[y];
+    });
+    HIPCHK(hipMemcpyAsync(tb + t_ord, order.data(), 4 * nb, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(tb + t_flags, 0, 64, s));
     uint32_t *status = (uint32_t *)(tb + t_st), *flags = (uint32_t *)(tb + t_flags);
     HIPCHK(ipx_launch_bgzf_inflate(s, h->bz_comp.as<uint8_t>(), (const uint64_t *)(tb + t_pb), (const uint64_t *)(tb + t_pe),
                                    (const uint32_t *)(tb + t_is), (const uint64_t *)(tb + t_oo), (const uint32_t *)(tb + t_crc), nb,
-                                   h->bz_out.as<uint8_t>(), h->bz_ws.as<uint32_t>(), status));
+                                   h->bz_out.as<uint8_t>(), h->bz_ws.as<uint32_t>(), status, (const uint32_t *)(tb + t_ord)));
     // flags[0] = unaligned, flags[1] = first bad block + 1 (inflate status or CRC), flags[2] = records in all
     HIPCHK(ipx_launch_bam_count_blocks(s, h->bz_out.as<uint8_t>(), (const uint64_t *)(tb + t_oo), (const uint32_t *)(tb + t_is), nb,
                                        f->records_begin, (uint32_t *)(tb + t_cnt), (uint32_t *)(tb + t_pre), (uint32_t *)(tb + t_sums),

@@ -370,9 +370,10 @@ hipError_t ipx_launch_bam_decode_cigar(hipStream_t s, const uint8_t *bytes, uint
 
 // ipx_inflate.hip: BGZF blocks inflated (and CRC-checked) on the device, records counted per block
 size_t ipx_bgzf_tables_bytes(uint64_t n_blocks);
+// order (device, n_blocks words, or null): the block the n-th lane takes -- longest first, so that a wave's lanes finish together
 hipError_t ipx_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end,
                                    const uint32_t *isize, const uint64_t *out_off, const uint32_t *crc, uint64_t n_blocks,
-                                   uint8_t *out, uint32_t *tables, uint32_t *status);
+                                   uint8_t *out, uint32_t *tables, uint32_t *status, const uint32_t *order);
 hipError_t ipx_launch_bam_count_blocks(hipStream_t s, const uint8_t *bytes, const uint64_t *out_off, const uint32_t *isize,
                                        uint64_t n_blocks, uint64_t records_begin, uint32_t *count, uint32_t *prefix, uint32_t *sums,
                                        uint32_t *total, uint64_t *span_begin, uint64_t *span_first, uint32_t *unaligned);

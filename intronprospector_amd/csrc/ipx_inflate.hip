@@ -7,7 +7,16 @@
 // in a private slice of global memory (they stay in L2), no cooperation between lanes.  RFC 1951 throughout:
 //   * codes of up to 10 bits (literal/length) or 8 bits (distance) through a direct table, longer ones through
 //     the canonical count/offset walk bit by bit (rare symbols).  (Tables of 9 / 7 bits in LDS, one column per lane,
-//     were slower: 328 against 222 ms on a 10 M-record BAM -- too many 10-bit codes.);
+//     were slower in round 2: 328 against 222 ms on a 10 M-record BAM -- too many 10-bit codes fell to the walk.  Round 4
+//     tried the full 10 / 8-bit tables in LDS, interleaved over the lanes, a wave per workgroup and all 160 KB of a CU:
+//     255 against 132 ms on the final kernel -- with one wave per CU only 256 of the file's 563 waves run at a time.)
+//   * A wave's turn takes as long as its slowest lane.  Round 4 (169 -> 132 ms, 12.9 -> 16.5 GB/s of inflated bytes): the
+//     walk BEHIND the direct table is arithmetic on counts held in a register and one load (LongCodes) where it was up to
+//     fifteen dependent loads; the input word behind the one just taken is asked for ahead of its use (Bits::ahead); a
+//     match copies unaligned 8-byte words, its last bytes from ONE more load, a run (distance < 8) from a register that is
+//     stored whole and rotated; literals are gathered into aligned 8-byte stores (OutBytes); the blocks are dealt to the
+//     lanes longest first (`order`).  What a turn still waits for is the table entry of every symbol -- a line of its own
+//     per lane, from a 73 MB working set -- and, most turns, some lane's symbol look-up behind the table.
 //   * every loop is bounded by the block's output size or a constant, every index is checked: a damaged stream
 //     ends in a status word, not in a fault or a wave that never finishes.
 // status[b]: 0 = inflated to exactly isize[b] bytes, otherwise an error code (1 bad block type / stored header,
@@ -16,6 +25,7 @@
 #include <stdint.h>
 
 #include "ipx_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,6 +47,11 @@ struct Bits {
     uint64_t buf;
     uint32_t cnt;
     uint32_t past;                // zero bytes supplied beyond `end`
+    // The word BEHIND the one fill() last took is asked for at once and kept in `ahead` (round 4): the next fill() finds it
+    // there instead of waiting a round trip for it -- a symbol's turn was two dependent round trips, the input word and the
+    // table entry its bits select.  (The buffers end in spare bytes: a word behind a block's last is readable.)
+    uint32_t ahead;
+    uint64_t ahead_at;            // the aligned address `ahead` was loaded from (~0: nothing loaded yet)
     // at least 33 bits (zeros beyond the end)
     __device__ __forceinline__ void fill() {
         while (cnt <= 32) {
@@ -48,7 +63,9 @@ struct Bits {
             }
             // the aligned word around pos, cut to the bytes of this block
             const uint64_t a = pos & ~3ull;
-            uint32_t w = *reinterpret_cast<const uint32_t *>(base + a);
+            uint32_t w = a == ahead_at ? ahead : *reinterpret_cast<const uint32_t *>(base + a);
+            ahead = *reinterpret_cast<const uint32_t *>(base + a + 4);
+            ahead_at = a + 4;
             const uint32_t skip = (uint32_t)(pos - a);                  // bytes of the word that lie before pos
             w >>= 8 * skip;
             uint32_t have = 4 - skip;                                   // bytes now in w
@@ -69,9 +86,27 @@ struct Bits {
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t code, uint32_t len) { return __brev(code) >> (32 - len); }
 
-// direct table (codes of at most `primary` bits) + sorted symbols and counts for the canonical walk; false: the
-// lengths over-subscribe the code space
-__device__ bool build(const uint8_t *lens, uint32_t n_sym, uint32_t primary, uint16_t *tab, uint16_t *sorted, uint16_t *cnt) {
+// a lane's direct tables: a slice of global memory (the LDS form that was tried: see the header)
+struct TabGlobal {
+    uint16_t *p;
+    __device__ __forceinline__ uint16_t get(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ void set(uint32_t i, uint16_t v) const { p[i] = v; }
+};
+
+// what the canonical walk needs of a code to go on BEHIND the direct table (round 4): the state of RFC 1951 3.2.2's count /
+// offset walk after `primary` bits -- no code that short matched, the table said so -- and the number of codes of every
+// greater length, nine bits each, in one register.  The walk behind the table is then at most five (literal / length) or
+// seven (distance) turns of arithmetic and ONE load, where it used to be up to fifteen dependent loads of cnt[] from the
+// lane's slice of global memory: and a wave's turn takes as long as its slowest lane -- with a few symbols in a hundred
+// longer than ten bits, some lane of the 64 was in that walk nearly every turn (~3 us per symbol).
+struct LongCodes {
+    unsigned long long counts;      // cnt[primary + 1 + k] at bits 9 k .. 9 k + 8
+    uint32_t first, index;          // `first` and `index` of the walk after length `primary`
+};
+
+template <class Tab>
+__device__ bool build(const uint8_t *lens, uint32_t n_sym, uint32_t primary, const Tab tab, uint16_t *sorted, uint16_t *cnt,
+                      LongCodes *lc = nullptr) {
     for (uint32_t l = 0; l < 16; ++l) cnt[l] = 0;
     for (uint32_t s = 0; s < n_sym; ++s) cnt[lens[s]]++;
     cnt[0] = 0;
@@ -90,8 +125,15 @@ __device__ bool build(const uint8_t *lens, uint32_t n_sym, uint32_t primary, uin
         code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
         next[l] = code;
     }
+    if (lc) {
+        uint32_t first = 0, index = 0;
+        for (uint32_t l = 1; l <= primary; ++l) { index += cnt[l]; first = (first + cnt[l]) << 1; }
+        unsigned long long packed = 0;
+        for (uint32_t l = primary + 1, k = 0; l < 16; ++l, ++k) packed |= (unsigned long long)cnt[l] << (9u * k);      // (cnt <= 288 < 512; k <= 6 for primary >= 8)
+        lc->counts = packed; lc->first = first; lc->index = index;
+    }
     const uint32_t size = 1u << primary;
-    for (uint32_t i = 0; i < size; ++i) tab[i] = 0xffffu;
+    for (uint32_t i = 0; i < size; ++i) tab.set(i, 0xffffu);
     for (uint32_t s = 0; s < n_sym; ++s) {
         const uint32_t l = lens[s];
         if (!l) continue;
@@ -100,18 +142,39 @@ __device__ bool build(const uint8_t *lens, uint32_t n_sym, uint32_t primary, uin
         if (l <= primary) {
             const uint32_t r = rev_bits(c, l);
             const uint16_t e = (uint16_t)(s | (l << 12));
-            for (uint32_t i = r; i < size; i += 1u << l) tab[i] = e;
+            for (uint32_t i = r; i < size; i += 1u << l) tab.set(i, e);
         }
     }
     return true;
 }
 
 // a symbol: through the direct table, or bit by bit (RFC 1951 3.2.2's canonical order); 0xffffffff: no such code
-__device__ __forceinline__ uint32_t decode(Bits &b, const uint16_t *tab, uint32_t primary, const uint16_t *sorted, const uint16_t *cnt) {
-    const uint32_t e = tab[b.peek(primary)];
+// (lc != nullptr: the walk goes on behind the table, see LongCodes; primary >= 8)
+template <class Tab>
+__device__ __forceinline__ uint32_t decode(Bits &b, const Tab tab, uint32_t primary, const uint16_t *sorted, const uint16_t *cnt,
+                                           const LongCodes *lc = nullptr) {
+    const uint32_t e = tab.get(b.peek(primary));
     if (e != 0xffffu) {
         b.drop(e >> 12);
         return e & 0x1ffu;
+    }
+    if (lc) {
+        uint32_t code = rev_bits(b.peek(primary), primary) << 1, first = lc->first, index = lc->index;
+        uint64_t bits = b.buf >> primary;
+        unsigned long long cc = lc->counts;
+        for (uint32_t l = primary + 1; l < 16; ++l, cc >>= 9) {
+            code |= (uint32_t)(bits & 1u);
+            bits >>= 1;
+            const uint32_t c = (uint32_t)cc & 0x1ffu;
+            if (code - first < c) {
+                b.drop(l);
+                return sorted[index + (code - first)];
+            }
+            index += c;
+            first = (first + c) << 1;
+            code <<= 1;
+        }
+        return 0xffffffffu;
     }
     uint32_t code = 0, first = 0, index = 0;
     uint64_t bits = b.buf;
@@ -130,23 +193,66 @@ __device__ __forceinline__ uint32_t decode(Bits &b, const uint16_t *tab, uint32_
     return 0xffffffffu;
 }
 
+// The output of a lane, literals gathered into aligned 8-byte stores.  `word` mirrors the aligned 8-byte word the next
+// byte falls into, from the first byte of it that is this lane's (w_own: 0 except in the word the block begins or a
+// match ended in) up to w_pos; a completed word that is wholly the lane's goes out in one store, anything else byte by
+// byte.  flush() makes memory current (a match is about to read it); after_copy() starts afresh behind bytes that a
+// match wrote to memory directly.
+struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };      // an 8-byte word at any address
+
+struct OutBytes {
+    uint8_t *o;
+    uint32_t n;                   // bytes produced so far (in memory or in `word`)
+    unsigned long long word;
+    uint32_t w_own, w_done, w_pos;         // w_done: bytes of the word already in memory
+    __device__ __forceinline__ void start(uint8_t *base) {
+        o = base; n = 0; word = 0;
+        w_own = w_done = w_pos = (uint32_t)((uintptr_t)base & 7u);
+    }
+    __device__ __forceinline__ void put(uint32_t byte) {
+        word |= (unsigned long long)byte << (8u * w_pos);
+        ++w_pos; ++n;
+        if (w_pos == 8u) {
+            uint8_t *w = o + n - 8u;                                       // the word's first byte (8-byte aligned)
+            if (w_own == 0u) *reinterpret_cast<unsigned long long *>(w) = word;
+            else for (uint32_t k = w_done; k < 8u; ++k) w[k] = (uint8_t)(word >> (8u * k));
+            word = 0; w_own = w_done = w_pos = 0u;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        uint8_t *w = o + n - w_pos;
+        for (uint32_t k = w_done; k < w_pos; ++k) w[k] = (uint8_t)(word >> (8u * k));
+        w_done = w_pos;
+    }
+    __device__ __forceinline__ void after_copy(uint32_t len) {           // `len` bytes were written to memory behind a flush()
+        n += len;
+        word = 0;
+        w_own = w_done = w_pos = (uint32_t)((uintptr_t)(o + n) & 7u);
+    }
+};
+
 // in_end == nullptr: block b's payload ends where block b + 1's begins (in_off has n_blocks + 1 entries)
+// order: the block a lane takes (null: its own number)
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
                                                      const uint64_t *__restrict__ in_end,
                                                      const uint32_t *__restrict__ isize, const uint64_t *__restrict__ out_off,
                                                      uint64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ status) {
-    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (blk >= n_blocks) return;
+                                                     uint32_t *__restrict__ status, const uint32_t *__restrict__ order) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= n_blocks) return;
+    const uint64_t blk = order ? order[gid] : gid;
     uint8_t *slice = reinterpret_cast<uint8_t *>(tables + blk * LANE_WORDS);
-    uint16_t *ll = reinterpret_cast<uint16_t *>(slice + O_LL), *dt = reinterpret_cast<uint16_t *>(slice + O_D);
+    const TabGlobal ll{reinterpret_cast<uint16_t *>(slice + O_LL)}, dt{reinterpret_cast<uint16_t *>(slice + O_D)};
     uint16_t *sll = reinterpret_cast<uint16_t *>(slice + O_SLL), *sd = reinterpret_cast<uint16_t *>(slice + O_SD);
     uint8_t *lens = slice + O_LENS;
     uint16_t *cll = reinterpret_cast<uint16_t *>(slice + O_CNT), *cd = cll + 16;
-    Bits b{comp, in_off[blk], in_end ? in_end[blk] : in_off[blk + 1], 0, 0, 0};
-    uint8_t *const o = out + out_off[blk];
+    Bits b{comp, in_off[blk], in_end ? in_end[blk] : in_off[blk + 1], 0, 0, 0, 0, ~0ull};
+    LongCodes lc_ll{0, 0, 0}, lc_d{0, 0, 0};
+    OutBytes ob;
+    ob.start(out + out_off[blk]);
+    uint8_t *const o = ob.o;
     const uint32_t cap = isize[blk];
-    uint32_t n_out = 0, err = 0;
+    uint32_t err = 0;
     for (uint32_t guard = 0; guard < 70000 && !err; ++guard) {            // a block of n bytes has at most n / 1 DEFLATE blocks worth looking at
         b.fill();
         const uint32_t final_block = b.take(1), type = b.take(2);
@@ -157,10 +263,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             b.fill();
             const uint32_t nlen = b.take(16);
             if ((len ^ nlen) != 0xffffu) { err = 1; break; }
-            if (n_out + len > cap) { err = 5; break; }
+            if (ob.n + len > cap) { err = 5; break; }
             for (uint32_t k = 0; k < len; ++k) {
                 b.fill();
-                o[n_out++] = (uint8_t)b.take(8);
+                ob.put(b.take(8));
             }
         } else if (type == 1 || type == 2) {
             if (type == 1) {
@@ -168,9 +274,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 for (uint32_t i = 144; i < 256; ++i) lens[i] = 9;
                 for (uint32_t i = 256; i < 280; ++i) lens[i] = 7;
                 for (uint32_t i = 280; i < 288; ++i) lens[i] = 8;
-                (void)build(lens, 288, LLB, ll, sll, cll);
+                (void)build(lens, 288, LLB, ll, sll, cll, &lc_ll);
                 for (uint32_t i = 0; i < 32; ++i) lens[i] = 5;
-                (void)build(lens, 32, DB, dt, sd, cd);
+                (void)build(lens, 32, DB, dt, sd, cd, &lc_d);
             } else {
                 b.fill();
                 const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
@@ -206,40 +312,70 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 if (err) break;
                 if (lens[256] == 0) { err = 2; break; }
                 // the distance lengths follow the literal/length ones in lens[]: build that table first, it moves nothing
-                if (!build(lens + hlit, hdist, DB, dt, sd, cd)) { err = 2; break; }
-                if (!build(lens, hlit, LLB, ll, sll, cll)) { err = 2; break; }
+                if (!build(lens + hlit, hdist, DB, dt, sd, cd, &lc_d)) { err = 2; break; }
+                if (!build(lens, hlit, LLB, ll, sll, cll, &lc_ll)) { err = 2; break; }
             }
             // symbols
             bool eob = false;
             for (uint32_t sguard = 0; sguard < 70000; ++sguard) {        // every symbol but the last writes a byte
                 b.fill();
-                const uint32_t sym = decode(b, ll, LLB, sll, cll);
+                const uint32_t sym = decode(b, ll, LLB, sll, cll, &lc_ll);
                 if (sym < 256) {
-                    if (n_out >= cap) { err = 5; break; }
-                    o[n_out++] = (uint8_t)sym;
+                    if (ob.n >= cap) { err = 5; break; }
+                    ob.put(sym);
                     continue;
                 }
                 if (sym == 256) { eob = true; break; }
                 if (sym > 285) { err = 3; break; }
                 const uint32_t len = C_LEN_BASE[sym - 257] + b.take(C_LEN_EXTRA[sym - 257]);
                 b.fill();
-                const uint32_t ds = decode(b, dt, DB, sd, cd);
+                const uint32_t ds = decode(b, dt, DB, sd, cd, &lc_d);
                 if (ds > 29) { err = 3; break; }
                 const uint32_t dist = C_DIST_BASE[ds] + b.take(C_DIST_EXTRA[ds]);
-                if (dist > n_out) { err = 4; break; }
-                if (n_out + len > cap) { err = 5; break; }
-                // eight bytes at a time where source and destination cannot overlap: the eight loads go out together
-                // (byte by byte every load waits for the store before it: ~1 us per byte)
-                uint32_t k = 0;
-                if (dist >= 8) {
-                    for (; k + 8 <= len; k += 8, n_out += 8) {
-                        const uint8_t *src = o + n_out - dist;
-                        const uint8_t b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3], b4 = src[4], b5 = src[5], b6 = src[6], b7 = src[7];
-                        uint8_t *dst = o + n_out;
-                        dst[0] = b0; dst[1] = b1; dst[2] = b2; dst[3] = b3; dst[4] = b4; dst[5] = b5; dst[6] = b6; dst[7] = b7;
+                if (dist > ob.n) { err = 4; break; }
+                if (ob.n + len > cap) { err = 5; break; }
+                ob.flush();                                              // the match reads what was produced so far from memory
+                // 8-byte words (unaligned: the hardware takes them) where a word's source ends before its destination begins;
+                // 32 bytes a turn, all four loads before the four stores, where that holds for the whole piece.  (Byte by
+                // byte every load waits for the store before it: ~1 us per byte; and the wave waits for its slowest lane.)
+                uint32_t k = 0, at = ob.n;
+                if (dist >= 32) {
+                    for (; k + 32 <= len; k += 32, at += 32) {
+                        const U64 *src = reinterpret_cast<const U64 *>(o + at - dist);
+                        const unsigned long long w0 = src[0].v, w1 = src[1].v, w2 = src[2].v, w3 = src[3].v;
+                        U64 *dst = reinterpret_cast<U64 *>(o + at);
+                        dst[0].v = w0; dst[1].v = w1; dst[2].v = w2; dst[3].v = w3;
                     }
                 }
-                for (; k < len; ++k, ++n_out) o[n_out] = o[n_out - dist];
+                if (dist >= 8) {
+                    for (; k + 8 <= len; k += 8, at += 8)
+                        reinterpret_cast<U64 *>(o + at)->v = reinterpret_cast<const U64 *>(o + at - dist)->v;
+                    // the last bytes: ONE more word loaded, its first bytes stored (byte by byte from memory every load waited
+                    // for the store before it -- up to seven round trips behind every match)
+                    if (k < len) {
+                        const unsigned long long w = reinterpret_cast<const U64 *>(o + at - dist)->v;
+                        for (uint32_t j = 0; k < len; ++k, ++at, ++j) o[at] = (uint8_t)(w >> (8u * j));
+                    }
+                } else {
+                    // source and destination overlap: the last `dist` bytes repeat.  They are loaded once (the word's other
+                    // bytes are whatever lies behind -- the output buffers end in spare bytes) and dealt out from the register.
+                    // (A run -- distance 1, a few hundred bytes -- byte by byte was a few hundred turns of a loop that 63 other
+                    // lanes waited for: the repeating bytes are spread over an 8-byte word that is stored whole and then turned
+                    // on by 8 mod dist places: two shifts, no memory.)
+                    unsigned long long w = reinterpret_cast<const U64 *>(o + at - dist)->v;
+                    const uint32_t db = 8u * dist;                       // 8 .. 56
+                    w &= (1ull << db) - 1ull;
+                    w |= w << db;                                          // 2 dist bytes
+                    if (2u * db < 64u) w |= w << (2u * db);                // 4 dist
+                    if (4u * db < 64u) w |= w << (4u * db);                // 8 dist (dist == 1)
+                    const uint32_t sh = 8u * (8u % dist);
+                    for (; k + 8 <= len; k += 8, at += 8) {
+                        reinterpret_cast<U64 *>(o + at)->v = w;
+                        if (sh) w = (w >> sh) | (w << (db - sh));
+                    }
+                    for (uint32_t j = 0; k < len; ++k, ++at, ++j) o[at] = (uint8_t)(w >> (8u * j));
+                }
+                ob.after_copy(len);
             }
             if (!err && !eob) err = 8;                                   // the guard ran out before an end-of-block symbol
         } else {
@@ -247,8 +383,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         }
         if (final_block || err) break;
     }
+    ob.flush();
     if (!err && b.past * 8 > b.cnt) err = 6;                            // bits were taken from beyond the block's end
-    if (!err && n_out != cap) err = 7;
+    if (!err && ob.n != cap) err = 7;
     status[blk] = err;
 }
 
@@ -322,11 +459,18 @@ __global__ __launch_bounds__(256) void k_span_first(const uint32_t *__restrict__
 
 size_t ipx_bgzf_tables_bytes(uint64_t n_blocks) { return (size_t)4 * LANE_WORDS * (n_blocks ? n_blocks : 1); }
 
+static void launch_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end, const uint32_t *isize,
+                           const uint64_t *out_off, uint64_t n_blocks, uint8_t *out, uint32_t *tables, uint32_t *status,
+                           const uint32_t *order) {
+    const dim3 grid((uint32_t)ipx_div_up(n_blocks, 64));
+    hipLaunchKernelGGL(k_bgzf_inflate, grid, dim3(64), 0, s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status, order);
+}
+
 hipError_t ipx_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end,
                                    const uint32_t *isize, const uint64_t *out_off, const uint32_t *crc, uint64_t n_blocks,
-                                   uint8_t *out, uint32_t *tables, uint32_t *status) {
+                                   uint8_t *out, uint32_t *tables, uint32_t *status, const uint32_t *order) {
     const dim3 grid((uint32_t)ipx_div_up(n_blocks, 64));
-    hipLaunchKernelGGL(k_bgzf_inflate, grid, dim3(64), 0, s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status);
+    launch_inflate(s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status, order);
     if (crc) hipLaunchKernelGGL(k_bgzf_crc, grid, dim3(64), 0, s, out, out_off, isize, crc, n_blocks, status);
     return hipGetLastError();
 }
@@ -371,8 +515,8 @@ extern "C" int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_
     }
     if (rc == IPX_OK) {
         ok(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k_bgzf_inflate, dim3((uint32_t)ipx_div_up(n_blocks, 64)), dim3(64), 0, nullptr, d_comp, d_in_off,
-                           (const uint64_t *)nullptr, d_isize, d_out_off, n_blocks, d_out, d_tables, d_status);
+        launch_inflate(nullptr, d_comp, d_in_off, (const uint64_t *)nullptr, d_isize, d_out_off, n_blocks, d_out, d_tables, d_status,
+                       (const uint32_t *)nullptr);
         ok(hipGetLastError());
         ok(hipEventRecord(e1, nullptr));
         ok(hipEventSynchronize(e1));

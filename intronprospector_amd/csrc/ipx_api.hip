@@ -10,6 +10,7 @@
 #include "ipx_reduce.h"
 
 #include <algorithm>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -190,10 +191,8 @@ int fail_hip(ipx_handle *h, hipError_t e, const char *what, int line) {
 // Waiting for the stream: the pipeline reads a few words back between its stages (record count and key
 // masks after the scan, segment counts after the sort, table sizes at the end), each a wait of well under
 // a millisecond.  Polling hipStreamQuery returns sooner than the blocking hipStreamSynchronize (which may
-// sleep until an interrupt); IPX_SYNC=block keeps the blocking wait.
+// sleep until an interrupt).
 static hipError_t ipx_stream_wait(hipStream_t s) {
-    static const bool block = [] { const char *e = getenv("IPX_SYNC"); return e && e[0] == 'b'; }();
-    if (block) return hipStreamSynchronize(s);
     hipError_t e;
     while ((e = hipStreamQuery(s)) == hipErrorNotReady) {
     }
@@ -244,9 +243,8 @@ __global__ void k_publish(const uint32_t *__restrict__ a, uint32_t na, const uin
 // halves so that a caller can leave between them (ipx_push_batch_async): begin queues the publication,
 // end waits for it and copies the words to dst.  One read-back at a time.
 int read_back_begin(ipx_handle *h, const void *a, uint32_t na, const void *b = nullptr, uint32_t nb = 0) {
-    static const bool by_copy = [] { const char *e = getenv("IPX_SYNC"); return e && (e[0] == 'b' || e[0] == 'c'); }();
     h->rb_words = na + nb;
-    h->rb_by_copy = by_copy || na + nb > MAIL_WORDS;
+    h->rb_by_copy = na + nb > MAIL_WORDS;          // more than the mailbox holds: a copy and a stream wait
     if (h->rb_by_copy) {
         if (na) HIPCHK(hipMemcpyAsync(h->pin_small, a, (size_t)na * 4, hipMemcpyDeviceToHost, h->stream));
         if (nb) HIPCHK(hipMemcpyAsync((uint32_t *)h->pin_small + na, b, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
@@ -443,6 +441,22 @@ GenomeDev genome_dev(const ipx_handle *h) {
 
 }  // namespace
 
+// the one-lane-per-operation scan (csrc/ipx_scan_ops.hip), from libipx_scanops.so beside this library; null: not there
+typedef hipError_t (*scanops_fn)(hipStream_t, const ScanParams *, const ipx_batch *, const uint32_t *, uint4 *, uint4 *, uint32_t *,
+                                 uint8_t *, uint64_t, Counters *);
+static scanops_fn scanops_entry() {
+    static const scanops_fn fn = []() -> scanops_fn {
+        Dl_info me;
+        if (!dladdr(reinterpret_cast<const void *>(&ipx_abi_version), &me) || !me.dli_fname) return nullptr;
+        std::string path(me.dli_fname);
+        const size_t slash = path.rfind('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "libipx_scanops.so";
+        void *lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        return lib ? reinterpret_cast<scanops_fn>(dlsym(lib, "ipx_scanops_launch")) : nullptr;
+    }();
+    return fn;
+}
+
 extern "C" {
 
 static int push_complete(ipx_handle *h);      // books a batch that ipx_push_batch_async left in flight
@@ -471,6 +485,13 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
         // the lane-per-alignment kernel (dependent loads per 64-word chunk): opt in with IPX_SCAN=ops.
         const char *e = getenv("IPX_SCAN");
         h->force_lane_scan = !(e && strcmp(e, "ops") == 0);
+        // (round 4: that kernel lives in libipx_scanops.so, next to this library, and is loaded only when asked for)
+        // a request for it that cannot be met is an error, not a quiet switch to the other kernel
+        if (!h->force_lane_scan && !scanops_entry()) {
+            fprintf(stderr, "ipx: IPX_SCAN=ops, but libipx_scanops.so is not beside libipx.so (build it: make -C intronprospector_amd/csrc)\n");
+            delete h;
+            return IPX_EINVAL;
+        }
     }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
     h->stream = h->own_stream;
@@ -604,11 +625,12 @@ static int launch_scan_attempt(ipx_handle *h) {
     PendingPush &pp = h->pending;
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
-    if (pp.use_ops)
-        HIPCHK(ipx_launch_scan_ops(h->stream, pp.sp, pp.db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
-                                   h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap,
-                                   h->counters.as<Counters>()));
-    else
+    if (pp.use_ops) {
+        HIPCHK(scanops_entry()(h->stream, &pp.sp, &pp.db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
+                               h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap,
+                               h->counters.as<Counters>()));
+        ipx_prof_mark(h->stream, IPXK_SCAN);
+    } else
         HIPCHK(ipx_launch_scan(h->stream, pp.sp, pp.db, h->d_rank_of_tid.as<uint32_t>(), h->items_a.as<uint4>(),
                                h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->rec_cap, h->counters.as<Counters>(),
                                h->n_records, pp.use_stripes ? h->close_ws.as<unsigned long long>() : nullptr, CLOSE_CAP,
@@ -1618,7 +1640,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     char *tb = h->bz_tab.as<char>();
     hipStream_t s = h->stream;
     // The file's bytes are the one large copy of this call.  Pageable memory goes through the runtime's staging
-    // buffers at a fraction of the link's rate: pin the caller's pages for the duration (IPX_BGZF_REGISTER=0: don't)
+    // buffers at a fraction of the link's rate: pin the caller's pages for the duration
     // (On every way out -- the early error returns included -- the stream is waited for before the caller's buffers are
     // let go: copies of the file's bytes and of the caller's block tables may still be under way, and the caller frees both
     // right after a failure: advisor, round 3.)
@@ -1631,8 +1653,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
         }
     } reg{s};
     {
-        static const bool want = [] { const char *e = getenv("IPX_BGZF_REGISTER"); return !(e && e[0] == '0'); }();
-        if (want && f->n_bytes >= (1u << 20) && hipHostRegister((void *)f->bytes, f->n_bytes, hipHostRegisterDefault) == hipSuccess)
+        if (f->n_bytes >= (1u << 20) && hipHostRegister((void *)f->bytes, f->n_bytes, hipHostRegisterDefault) == hipSuccess)
             reg.p = (void *)f->bytes;
         else
             (void)hipGetLastError();

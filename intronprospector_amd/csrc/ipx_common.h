@@ -319,8 +319,8 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
                            unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer, uint32_t rest_hint);
-// ipx_scan_ops.hip: the same scan with one lane per CIGAR operation (needs back-to-back CIGAR
-// words; raises Counters::pad[0] otherwise and the caller re-runs ipx_launch_scan)
+// ipx_scan_ops.hip (built into libipx_scanops.so, not into libipx.so): the same scan with one lane per CIGAR operation
+// (needs back-to-back CIGAR words; raises Counters::pad[0] otherwise and the caller re-runs ipx_launch_scan)
 hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_batch &b,
                                const uint32_t *rank_of_tid, uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs,
                                uint64_t capacity, Counters *counters);

@@ -695,9 +695,8 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
     const uint32_t identity = genome.seq_of_rank == nullptr ? 1u : 0u;
     // ... and the bins' offsets and counts are written where the table has them (no k_emit_bins)
     uint32_t *bin_count = identity ? rb.out_hist_count : rb.bin_count;
-    // IPX_FUSE_HEADS=0: k_write_heads in every mode (tests run both)
-    const char *fuse_e = getenv("IPX_FUSE_HEADS");
-    const bool fuse_heads = identity && !(fuse_e && fuse_e[0] == '0');
+    // (k_write_heads is the path of a run with a genome; without one the descriptors come from k_reduce<0>)
+    const bool fuse_heads = identity;
     HeadOut ho{};
     if (fuse_heads) {
         const uint64_t cells = (uint64_t)J + B;

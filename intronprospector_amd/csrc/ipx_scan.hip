@@ -2085,7 +2085,8 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     // S's alignments: 85 of 256 fill 1.3 waves, 170 of 512 fill 2.7): 0.287 -> 0.263 ms.  The grid is what is
     // resident at once (96 VGPRs, 5 waves per SIMD), every block loops over tiles: fewer blocks leave CUs idle,
     // more add a ragged last round and more end-of-block atomics on the key masks.
-    static const uint32_t short_bt = [] { const char *e = getenv("IPX_SHORT_BT"); const long v = e ? atol(e) : 0; return (uint32_t)(v == 128 ? 128 : v == 64 ? 64 : 256); }();
+    // (rounds 1-3 could pick 64- and 128-thread blocks through IPX_SHORT_BT; both measured slower, retired in round 4)
+    constexpr uint32_t short_bt = 256;
     static const uint32_t n_cus = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -2093,8 +2094,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     }();
     const uint64_t per_tile = short_reads ? 2ull * short_bt : 256;
     uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
-    static const uint64_t max_blocks = [] { const char *e = getenv("IPX_SCAN_BLOCKS"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
-    const uint64_t resident = max_blocks ? max_blocks : (uint64_t)n_cus * (1280u / short_bt);
+    const uint64_t resident = (uint64_t)n_cus * (1280u / short_bt);
     if (blocks > resident) blocks = resident;
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     ipx_prof_pre(s, IPXK_SCAN);
@@ -2102,28 +2102,15 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                        reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_DEFER),
                        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED));
     // stripes pay once many blocks queue on the record counter
-    static const bool no_stripes = [] { const char *e = getenv("IPX_STRIPES"); return e && e[0] == '0'; }();
     p.base = n_records_before;
-    p.n_stripes = (blocks >= 64 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
-    if (short_reads && short_bt == 256)
+    p.n_stripes = (blocks >= 64 && close_ws && close_cap) ? IPX_STRIPES : 0;
+    if (short_reads)
         hipLaunchKernelGGL((k_scan_short<2, 768, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
-                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
-    else if (short_reads && short_bt == 64)
-        hipLaunchKernelGGL((k_scan_short<2, 192, 64>), dim3((uint32_t)blocks), dim3(64), 0, s, p, b.n_alignments,
-                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
-    else if (short_reads)
-        hipLaunchKernelGGL((k_scan_short<2, 384, 128>), dim3((uint32_t)blocks), dim3(128), 0, s, p, b.n_alignments,
                            b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
                            b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
     else {
         // long CIGARs: waves work through ranges of >= 64 alignments
-        static const uint32_t min_range = [] {
-            const char *e = getenv("IPX_LONG_RANGE");
-            const long v = e ? atol(e) : 0;
-            return (uint32_t)(v >= 64 && v <= 65536 ? v : 64);
-        }();
+        constexpr uint32_t min_range = 64;
         const char *lv = getenv("IPX_LONG");
         // k_scan_long3 reads aligned 64-byte pieces of the CIGAR array and counts its words in 32 bits
         const bool v3 = !(lv && lv[0] == '1') && ((uintptr_t)b.cigar & 15u) == 0 && b.n_cigar_words < (1ull << 31);
@@ -2133,18 +2120,17 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         // few alignments per lane: whole multiples of 64, or one lane's second alignment doubles the wave's time
         if (per_wave < 256) per_wave = (per_wave + 63) / 64 * 64;
         const uint64_t waves = ipx_div_up(b.n_alignments, per_wave);
-        p.n_stripes = (waves >= 256 && close_ws && close_cap && !no_stripes) ? IPX_STRIPES : 0;
+        p.n_stripes = (waves >= 256 && close_ws && close_cap) ? IPX_STRIPES : 0;
         // IPX_LONG=1: k_scan_long instead of k_scan_long3 (tests run both).  Round 2 also built a two-speed walk
         // (k_scan_long2: chunks of four plain ops on a fast path, lanes that met anything else waited for 40 others;
         // exact, 6.5 ms against 5.1 at 2 M alignments) -- DESIGN.md section 4 has the measurement, the history has the code
-        const char *lp = getenv("IPX_LONG_PAD");                  // experiment: extra LDS per block = fewer waves per CU
-        const uint32_t pad = lp ? (uint32_t)atol(lp) : 0u;
+        // (IPX_LONG_PAD, the round-2 occupancy experiment's extra LDS per block, retired in round 4: NOTEBOOK.md)
         if (v3)
-            hipLaunchKernelGGL(k_scan_long3, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
+            hipLaunchKernelGGL(k_scan_long3, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
         else
-            hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), pad, s, p, b.n_alignments,
+            hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
     }

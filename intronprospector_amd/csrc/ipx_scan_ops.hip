@@ -463,6 +463,14 @@ hipError_t ipx_launch_scan_ops(hipStream_t s, const ScanParams &p, const ipx_bat
     uint64_t blocks = ipx_div_up(waves, 4);
     if (blocks > 256ull * 32) blocks = 256ull * 32;
     hipLaunchKernelGGL(k_scan_ops, dim3((uint32_t)blocks), dim3(256), 0, s, a);
-    ipx_prof_mark(s, IPXK_SCAN);
     return hipGetLastError();
+}
+
+// This file is NOT part of libipx.so (round 4): the per-operation scan is an alternative formulation that measured 3-4
+// times slower than the lane-per-alignment kernels; it is built into libipx_scanops.so, which
+// libipx.so loads at ipx_create when IPX_SCAN=ops asks for it (tests/test_gpu_parity.py keeps its parity test).
+extern "C" hipError_t ipx_scanops_launch(hipStream_t s, const ScanParams *p, const ipx_batch *b, const uint32_t *rank_of_tid,
+                                         uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs, uint64_t capacity,
+                                         Counters *counters) {
+    return ipx_launch_scan_ops(s, *p, *b, rank_of_tid, items, pays, cnts, digs, capacity, counters);
 }

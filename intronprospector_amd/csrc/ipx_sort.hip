@@ -496,16 +496,15 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
     const bool bytes = dig_a != nullptr && dig_b != nullptr;
     // small tiles: 8 per histogram block (16 KiB of digit bytes) once that leaves >= 256 blocks; large
     // tiles: one (measured on S, per step of 8 passes: 1 tile 0.106 ms, 2 0.114, 4 0.118, 8 0.134)
-    const char *ge = getenv("IPX_HIST_GROUP");
-    const uint32_t group = ge ? (uint32_t)atoi(ge) : (big ? 1u : 8u);
+    const uint32_t group = big ? 1u : 8u;
     const bool grouped = (uint64_t)n_tiles * tile_items >= (4u << 20);
     const uint32_t n_groups = grouped ? (n_tiles + group - 1) / group : n_tiles;
     const uint32_t hist_grid = n_groups <= 8192 ? n_groups : 2048;      // one block per group while that is cheap
     uint4 *src = buf_a, *dst = buf_b;
     uint8_t *dsrc = dig_a, *ddst = dig_b;
-    static const uint32_t xcd_env = [] { const char *e = getenv("IPX_SCATTER_XCD"); return e ? (uint32_t)atoi(e) : 1u; }();
-    const uint32_t xcd_ranges = (xcd_env && n_tiles >= 64) ? 1u : 0u;
-    static const uint32_t scatter_nt = [] { const char *e = getenv("IPX_SCATTER_NT"); return e ? (uint32_t)atoi(e) : 512u; }();
+    // tiles dealt to the XCDs in contiguous ranges, 512 threads on the 2048-item tile: the measured winners of rounds
+    // 1-3 (blockIdx order and 256 threads were IPX_SCATTER_XCD=0 / IPX_SCATTER_NT=256 until round 4; NOTEBOOK.md)
+    const uint32_t xcd_ranges = n_tiles >= 64 ? 1u : 0u;
     for (uint32_t k = 0; k < plan.n; ++k) {
         const DigitSpec d = plan.digits[k];
         const bool has_next = k + 1 < plan.n || after_last != nullptr;
@@ -513,11 +512,7 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
         const bool from_bytes = bytes && (k > 0 || first_bytes_valid);
 #define IPX_HIST(B, G, T) hipLaunchKernelGGL((k_hist<B, G, T>), dim3(hist_grid), dim3(SORT_THREADS), 0, s, src, dsrc, n, d, hist, n_tiles)
         if (big) {
-            if (from_bytes && grouped && group == 2) IPX_HIST(true, 2, 4096);
-            else if (from_bytes && grouped && group == 1) IPX_HIST(true, 1, 4096);
-            else if (from_bytes && grouped && group == 8) IPX_HIST(true, 8, 4096);
-            else if (from_bytes && grouped) IPX_HIST(true, 4, 4096);
-            else if (from_bytes) IPX_HIST(true, 1, 4096);
+            if (from_bytes) IPX_HIST(true, 1, 4096);
             else if (grouped) IPX_HIST(false, 4, 4096);
             else IPX_HIST(false, 1, 4096);
         } else {
@@ -536,10 +531,8 @@ hipError_t ipx_launch_sort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *d
         const bool w = bytes && has_next;
         if (big) {
             if (w) IPX_SCATTER(true, 1024, 4096); else IPX_SCATTER(false, 1024, 4096);
-        } else if (scatter_nt == 512) {
-            if (w) IPX_SCATTER(true, 512, 2048); else IPX_SCATTER(false, 512, 2048);
         } else {
-            if (w) IPX_SCATTER(true, 256, 2048); else IPX_SCATTER(false, 256, 2048);
+            if (w) IPX_SCATTER(true, 512, 2048); else IPX_SCATTER(false, 512, 2048);
         }
 #undef IPX_SCATTER
         ipx_prof_mark(s, prof_all >= 0 ? prof_all : IPXK_SORT_SCATTER);

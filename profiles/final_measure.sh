@@ -16,5 +16,5 @@ done
 echo progress: profiles done
 python profiles/fuzz_campaign.py 1200 300000 > $O/fuzz_default.log 2>&1
 IPX_LONG=1 IPX_COMBINE=0 python profiles/fuzz_campaign.py 300 310000 > $O/fuzz_long1_nocombine.log 2>&1
-IPX_FUSE_HEADS=0 IPX_SHORT_MAX_AVG=16 python profiles/fuzz_campaign.py 300 320000 > $O/fuzz_nofuse_short16.log 2>&1
+IPX_SHORT_MAX_AVG=16 python profiles/fuzz_campaign.py 300 320000 > $O/fuzz_short16.log 2>&1
 for f in $O/fuzz_*.log; do tail -n 1 $f; done

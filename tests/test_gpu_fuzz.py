@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("first_seed,env", [(20_000, {}), (21_000, {"IPX_SHORT_MAX_AVG": "16"}),
-                                            (22_000, {"IPX_SORT_TILE": "4096", "IPX_STRIPES": "0"}),
+                                            (22_000, {"IPX_SORT_TILE": "4096"}),
                                             (23_000, {"IPX_LONG": "1", "IPX_COMBINE": "0"})])
 def test_fuzz_slice(first_seed, env, oracle_lib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fuzz_campaign.py"), "60", str(first_seed)],

@@ -475,7 +475,7 @@ def run_m(args, rank, world, local_rank):
     import torch.distributed as dist
     import intronprospector_amd as ipa
     from intronprospector_amd import config5, distributed, synth, _lib as L
-    from intronprospector_amd.distributed import RecordExchanger, SlotOverflow, table_to_torch, _all_gather_var
+    from intronprospector_amd.distributed import RecordExchanger, table_to_torch, _all_gather_var
     if args.backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -512,7 +512,6 @@ def run_m(args, rank, world, local_rank):
             self.cur = self.ex
             self.xch = RecordExchanger(dev, comm_device=comm_dev)
             self.xch.strict = False
-            self.rescans = 0
             self.n_items = 0
 
         def scan(self, h):
@@ -538,12 +537,9 @@ def run_m(args, rank, world, local_rank):
                 th.start()
                 self.ahead = (nxt, th)
             self.n_items = self.cur.records_pending()
-            while True:
-                try:
-                    return self.xch.run(self.cur, self.n)
-                except SlotOverflow:                  # (sizes come from the batch before; a larger batch is scanned again)
-                    self.rescans += 1
-                    self.scan(self.cur)
+            # (a batch that outgrows the slots sized from the one before is completed by a second all_to_all inside run():
+            # xch.slot_overflows counts those; nothing is scanned twice)
+            return self.xch.run(self.cur, self.n)
 
         def close(self):
             if self.ahead is not None:
@@ -574,7 +570,7 @@ def run_m(args, rank, world, local_rank):
     elapsed, (table, ijunc) = main_s.timed(args.steps, args.warmup)
     t = table_to_torch(main_s.cur, table, "cpu")
     checks = config5.cross_rank_checks(t, ijunc.cpu(), int(table.n_records), group=cpu_group)
-    checks["slot_overflow_rescans"] = main_s.rescans
+    checks["slot_overflows_completed_by_second_all_to_all"] = main_s.xch.slot_overflows
     per_rank = {"alignments": main_s.n, "cigar_words": main_s.n_words, "records_after_combine": int(main_s.n_items),
                 "pushes": len(main_s.pieces), "generate_s": main_s.generate_s}
     # kernel classes of one more step (of the handle whose turn it is)
@@ -820,13 +816,7 @@ def main():
         n_items[0] = cur.records_pending()
         if exchanger is not None:
             # junction records -> key-range owners over RCCL (all_to_all), then the local finalize
-            from intronprospector_amd.distributed import SlotOverflow
-            while True:
-                try:
-                    table, ijunc = exchanger.run(cur, n)
-                    break
-                except SlotOverflow:              # (sizes come from the batch before; a larger batch is scanned again)
-                    scan(cur)
+            table, ijunc = exchanger.run(cur, n)
             n_records[0] = table.n_records
             n_merged[0] = int(table.n_junctions)          # this rank's key range; summed after the timed loop
             return table

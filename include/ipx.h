@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IPX_ABI_VERSION 3
+#define IPX_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -373,6 +373,20 @@ int ipx_records_partition_slots(ipx_handle *h, uint32_t n_parts, const uint64_t 
                                 uint64_t error_order, int32_t error_status, void *dst_slots);
 int ipx_records_adopt_slots(ipx_handle *h, uint32_t n_slots, uint64_t slot_records, const void *slots,
                             uint64_t n_alignments, ipx_slots_info *info);
+/* Overflow without a second scan (ABI 4).  ipx_records_partition_slots_spill is ipx_records_partition_slots that also
+ * keeps what a slot cannot hold: the records of part p beyond its slot's room (slot_records - header) go to dst_spill
+ * (device memory, spill_records records of 32 bytes; room for ipx_records_pending records is always enough), the tail of
+ * part 0 first, then part 1's, ...  After ipx_records_adopt_slots said overflow, the true counts of every sender for
+ * every part stand in the received headers (32-bit words from byte 32 of a slot on), so every rank knows how long each
+ * tail is: a second all-to-all with those lengths brings the tails to their owners and
+ *   ipx_records_adopt_more   appends n received records to the pending ones (after ipx_records_adopt_slots or
+ *                            ipx_records_adopt; key masks and read counts go on from there)
+ * -- the table is then the same as if the slots had been large enough.  (src/junctions_extractor.cc:466-485: every
+ * record is counted once, whichever way it travelled.) */
+int ipx_records_partition_slots_spill(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t slot_records,
+                                      uint64_t error_order, int32_t error_status, void *dst_slots, void *dst_spill,
+                                      uint64_t spill_records);
+int ipx_records_adopt_more(ipx_handle *h, uint64_t n, const void *records);
 /* Run everything the handle queues on the caller's HIP stream (hipStream_t; NULL: back to the handle's own), e.g. the
  * stream a torch.distributed collective is ordered on.  Waits for what the handle had queued before.  NULL never means
  * the null stream: a caller that wants the legacy null stream names it, hipStreamLegacy ((hipStream_t)1) -- a handle

@@ -30,7 +30,7 @@ SYMBOLS = [
     "ipx_group_last_error", "ipx_group_uses_rccl",
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
     "ipx_push_bam", "ipx_push_bam_async", "ipx_bgzf_inflate",
-    "ipx_records_partition_slots", "ipx_records_adopt_slots", "ipx_use_stream", "ipx_copy_async", "ipx_decode_bgzf",
+    "ipx_records_partition_slots", "ipx_records_adopt_slots", "ipx_records_partition_slots_spill", "ipx_records_adopt_more", "ipx_use_stream", "ipx_copy_async", "ipx_decode_bgzf",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -138,6 +138,8 @@ def load():
     lib.ipx_records_adopt.argtypes = [vp, C.c_uint64, vp, C.c_uint64]
     lib.ipx_records_partition_slots.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int32, vp]
     lib.ipx_records_adopt_slots.argtypes = [vp, C.c_uint32, C.c_uint64, vp, C.c_uint64, C.POINTER(SlotsInfo)]
+    lib.ipx_records_partition_slots_spill.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_int32, vp, vp, C.c_uint64]
+    lib.ipx_records_adopt_more.argtypes = [vp, C.c_uint64, vp]
     lib.ipx_use_stream.argtypes = [vp, vp]
     lib.ipx_decode_bgzf.argtypes = [vp, C.POINTER(BgzfFile), C.POINTER(Batch)]
     lib.ipx_copy_async.argtypes = [vp, vp, vp, C.c_uint64]

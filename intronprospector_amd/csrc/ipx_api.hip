@@ -1532,7 +1532,14 @@ static int stage_splitters(ipx_handle *h, uint32_t n_parts, const uint64_t *spli
 
 int ipx_records_partition_slots(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t slot_records,
                                 uint64_t error_order, int32_t error_status, void *dst_slots) {
+    return ipx_records_partition_slots_spill(h, n_parts, splitters, slot_records, error_order, error_status, dst_slots, nullptr, 0);
+}
+
+int ipx_records_partition_slots_spill(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, uint64_t slot_records,
+                                      uint64_t error_order, int32_t error_status, void *dst_slots, void *dst_spill,
+                                      uint64_t spill_records) {
     if (!h || !n_parts || n_parts > 64 || (n_parts > 1 && !splitters) || slot_records < 2 + (n_parts + 7) / 8 || !dst_slots) return IPX_EINVAL;
+    if (!dst_spill) spill_records = 0;
     (void)hipSetDevice(h->params.device);
     { const int prc = push_complete(h); if (prc) return prc; }
     const uint32_t blocks = ipx_partition_blocks(h->n_records);
@@ -1543,7 +1550,7 @@ int ipx_records_partition_slots(ipx_handle *h, uint32_t n_parts, const uint64_t 
     ipx_prof_mark(h->stream, IPXK_BEGIN);
     HIPCHK(ipx_launch_partition_slots(h->stream, h->items_a.as<uint4>(), h->pays.as<uint4>(), h->cnts.as<uint32_t>(), h->n_records,
                                       h->key, n_parts, d_spl, d_blk, d_cnt, slot_records, error_order, (uint32_t)error_status,
-                                      (uint4 *)dst_slots));
+                                      (uint4 *)dst_slots, spill_records ? (uint4 *)dst_spill : nullptr, spill_records));
     return IPX_OK;
 }
 
@@ -1593,6 +1600,29 @@ int ipx_records_adopt_slots(ipx_handle *h, uint32_t n_slots, uint64_t slot_recor
     h->n_records = info->n_records;
     h->n_raw = info->n_records + merged;
     h->n_alignments = n_alignments;
+    return IPX_OK;
+}
+
+int ipx_records_adopt_more(ipx_handle *h, uint64_t n, const void *records) {
+    if (!h || (n && !records)) return IPX_EINVAL;
+    if (!n) return IPX_OK;
+    (void)hipSetDevice(h->params.device);
+    { const int prc = push_complete(h); if (prc) return prc; }
+    int rc;
+    if ((rc = grow_records(h, h->n_records + n))) return rc;
+    ProfScope prof_scope(&h->prof);
+    ipx_prof_mark(h->stream, IPXK_BEGIN);
+    // the counters go on from where the adoption before left them: key masks accumulate, the merged-reads count too
+    unsigned long long *merged_dev = reinterpret_cast<unsigned long long *>(h->counters.as<char>() + IPX_CNT_MERGED);
+    HIPCHK(ipx_launch_adopt(h->stream, (const uint4 *)records, n, h->n_records, h->items_a.as<uint4>(), h->pays.as<uint4>(),
+                            h->cnts.as<uint32_t>(), h->dig_a.as<uint8_t>(), h->first_window, h->counters.as<Counters>()));
+    if ((rc = read_back(h, h->pin_small, h->counters.p, sizeof(Counters) / 4, merged_dev, 2))) return rc;
+    h->prof.collect();
+    const Counters *c = (const Counters *)h->pin_small;
+    const uint32_t *m2 = (const uint32_t *)h->pin_small + sizeof(Counters) / 4;
+    for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
+    h->n_records += n;
+    h->n_raw = h->n_records + ((uint64_t)m2[0] | ((uint64_t)m2[1] << 32));
     return IPX_OK;
 }
 

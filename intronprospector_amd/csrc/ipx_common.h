@@ -396,7 +396,8 @@ hipError_t ipx_launch_adopt(hipStream_t s, const uint4 *records, uint64_t n, uin
 hipError_t ipx_launch_partition_slots(hipStream_t s, const uint4 *items, const uint4 *pays, const uint32_t *cnts, uint64_t n,
                                       const KeyLayout &kl, uint32_t n_parts, const unsigned long long *splitters,
                                       unsigned long long *blk, unsigned long long *totals, uint64_t slot_records,
-                                      unsigned long long error_order, uint32_t error_status, uint4 *out_slots);
+                                      unsigned long long error_order, uint32_t error_status, uint4 *out_slots,
+                                      uint4 *spill = nullptr, uint64_t spill_records = 0);
 hipError_t ipx_launch_adopt_slots(hipStream_t s, const uint4 *slots, uint32_t n_slots, uint64_t slot_records, uint64_t first_index,
                                   uint4 *items, uint4 *pays, uint32_t *cnts, uint8_t *digs, DigitSpec first, Counters *counters,
                                   uint32_t *info /* device, 16 words */);

@@ -113,12 +113,22 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ 
                                                       uint64_t n, KeyLayout kl, uint32_t n_parts,
                                                       const unsigned long long *__restrict__ spl_g,
                                                       const unsigned long long *__restrict__ blk,
-                                                      uint4 *__restrict__ out, uint64_t slot_records) {
+                                                      uint4 *__restrict__ out, uint64_t slot_records,
+                                                      const unsigned long long *__restrict__ totals,
+                                                      uint4 *__restrict__ spill, uint64_t spill_records) {
     __shared__ unsigned long long spl[MAX_PARTS];
     __shared__ unsigned long long cursor[MAX_PARTS];        // this block's next position per part
+    __shared__ unsigned long long spill_base[MAX_PARTS];    // slots with a spill: where part p's tail begins in it
     if (threadIdx.x < MAX_PARTS) {
         spl[threadIdx.x] = (threadIdx.x + 1 < n_parts) ? spl_g[threadIdx.x] : ~0ull;
         cursor[threadIdx.x] = blk[(uint64_t)blockIdx.x * MAX_PARTS + threadIdx.x];
+        unsigned long long before = 0;
+        if (spill && slot_records) {
+            // (totals: written by k_part_plan_slots, the launch before this one)
+            const unsigned long long room = slot_records - slot_header_records(n_parts);
+            for (uint32_t q = 0; q < threadIdx.x && q < n_parts; ++q) before += totals[q] > room ? totals[q] - room : 0ull;
+        }
+        spill_base[threadIdx.x] = before;
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -144,13 +154,22 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ 
                     pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 todo &= ~m;
             }
-            // (slots: a part's records beyond its slot are not sent; the header says so and the exchange is repeated)
+            // (slots: a part's records beyond its slot go to the spill, part after part -- the header says that there are
+            // some and a second all-to-all brings them over; without a spill they are not sent and the caller repeats)
             if (ok && (slot_records == 0 || pos < ((unsigned long long)part + 1) * slot_records)) {      // (a slot's header lies below its first position)
                 // on the way the item's fourth word (the record index, meaningless elsewhere) carries the count word
                 const uint4 py = pays[it.w];
                 it.w = cnts[it.w];
                 out[2 * pos] = it;
                 out[2 * pos + 1] = py;
+            } else if (ok && spill) {
+                const unsigned long long at = spill_base[part] + (pos - ((unsigned long long)part + 1) * slot_records);
+                if (at < spill_records) {         // (the caller gives room for every record; a smaller spill loses the rest -- its header says overflow all the same)
+                    const uint4 py = pays[it.w];
+                    it.w = cnts[it.w];
+                    spill[2 * at] = it;
+                    spill[2 * at + 1] = py;
+                }
             }
         }
     }
@@ -367,7 +386,7 @@ hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *
     hipLaunchKernelGGL(k_part_plan, dim3(1), dim3(1024), 0, s, blk, blocks, n_parts, totals);
     if (n)
         hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(256), 0, s, items, pays, cnts, n, kl, n_parts, splitters, blk,
-                           out_records, (uint64_t)0);
+                           out_records, (uint64_t)0, (const unsigned long long *)nullptr, (uint4 *)nullptr, (uint64_t)0);
     ipx_prof_mark(s, IPXK_PARTITION);
     return hipGetLastError();
 }
@@ -375,7 +394,8 @@ hipError_t ipx_launch_partition(hipStream_t s, const uint4 *items, const uint4 *
 hipError_t ipx_launch_partition_slots(hipStream_t s, const uint4 *items, const uint4 *pays, const uint32_t *cnts, uint64_t n,
                                       const KeyLayout &kl, uint32_t n_parts, const unsigned long long *splitters,
                                       unsigned long long *blk, unsigned long long *totals, uint64_t slot_records,
-                                      unsigned long long error_order, uint32_t error_status, uint4 *out_slots) {
+                                      unsigned long long error_order, uint32_t error_status, uint4 *out_slots,
+                                      uint4 *spill, uint64_t spill_records) {
     if (n_parts > MAX_PARTS || slot_records <= slot_header_records(n_parts)) return hipErrorInvalidValue;
     const uint32_t blocks = ipx_partition_blocks(n);
     hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(256), 0, s, items, n, kl, n_parts, splitters, blk);
@@ -383,7 +403,7 @@ hipError_t ipx_launch_partition_slots(hipStream_t s, const uint4 *items, const u
                        totals, out_slots);
     if (n)
         hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(256), 0, s, items, pays, cnts, n, kl, n_parts, splitters, blk,
-                           out_slots, slot_records);
+                           out_slots, slot_records, (const unsigned long long *)totals, spill, spill_records);
     ipx_prof_mark(s, IPXK_PARTITION);
     return hipGetLastError();
 }

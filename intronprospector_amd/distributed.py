@@ -286,6 +286,7 @@ class RecordExchanger:
         self.slotted = True              # False: always the exact exchange (tests compare both)
         self._slot_records = None        # records per slot of the slotted exchange (None: not known yet)
         self._send = self._recv = None
+        self._spill = self._tails = None
         self._stream = None              # the slotted exchange's own stream (see _run_slotted)
         self.slot_overflows = 0
         self.strict = True               # look at the ranks' finalize errors at the end of every run (False: check_last())
@@ -313,8 +314,9 @@ class RecordExchanger:
         with a margin, parts travel in fixed-capacity slots whose headers carry the true counts, an overflow flag and
         the ranks' errors (ipx_records_partition_slots), so ONE all_to_all with equal splits needs no counts collective
         and no read-back before it; the creation orders are gathered at a fixed length too.  A batch that outgrows
-        its slots raises SlotOverflow after the sizes were raised: the caller scans the batch again and calls run()
-        once more (nothing of the cut-short exchange is kept)."""
+        its slots is completed by a SECOND all_to_all (round 4): the partition kept every part's tail in a spill, the
+        headers carry every sender's true counts, so all ranks know the tails' lengths without asking; the slots are
+        raised for the next batch.  (Rounds 2-3 raised SlotOverflow here and the caller scanned the batch again.)"""
         if (self._splitters is None or not self.reuse_splitters or self._slot_records is None or not self.slotted
                 or len(self._splitters) != dist.get_world_size(self.group) - 1):
             return self._run_exact(ex, n_alignments_local)
@@ -377,9 +379,14 @@ class RecordExchanger:
             self._send = torch.empty(need, dtype=torch.uint8, device=self.device)
             self._recv = torch.empty(need, dtype=torch.uint8, device=self.device)
         send, recv = self._send[:need], self._recv[:need]
+        # the spill: room for every record this rank holds (the worst case: all of them beyond their slots)
+        n_local = ex.records_pending() if failed is None else 0
+        if self._spill is None or self._spill.numel() < max(n_local, 1) * 32:
+            self._spill = torch.empty(max(n_local, 1) * 32 * 5 // 4, dtype=torch.uint8, device=self.device)
         try:
             ex.records_partition_slots(self._splitters, S, send.data_ptr(),
-                                       failed.order if failed else ERR_NONE, failed.status if failed else 0)
+                                       failed.order if failed else ERR_NONE, failed.status if failed else 0,
+                                       spill_ptr=self._spill.data_ptr(), spill_records=self._spill.numel() // 32)
         except IpxError as exc:                  # (arguments, memory: not about the data) -- empty slots that say so
             failed = ShardError.from_ipx(exc)
             send.zero_()
@@ -402,9 +409,9 @@ class RecordExchanger:
         if info.error_order != ERR_NONE or (failed is not None):
             agree_on_error(failed, self.group, self.comm_device)
         if info.overflow:
-            self._slot_records = int(info.max_part * self.SLOT_MARGIN) + 64
             self.slot_overflows += 1
-            raise SlotOverflow(self._slot_records)
+            self._exchange_tails(ex, world, S, recv)
+            t0 = self._lap("tails", t0)
         # keep the slots a margin above what the data needs (they shrink slowly, grow at once)
         want = int(info.max_part * self.SLOT_MARGIN) + 64
         self._slot_records = want if want > S else max(want, int(S * 0.9))
@@ -445,6 +452,30 @@ class RecordExchanger:
             self.check_last()
         t0 = self._lap("global_ijunc", t0)
         return table, ijunc
+
+    def _exchange_tails(self, ex, world, S, recv):
+        """The slots were too small for some part: bring over what the partition left in the spill.  Every header holds
+        its sender's counts for ALL parts (ipx_exchange.hip: k_part_plan_slots), and every rank received one slot from
+        every sender, so the whole counts matrix is here already -- one small read-back, no counts collective."""
+        rank = dist.get_rank(self.group)
+        header_records = 1 + (world + 7) // 8
+        room = S - header_records
+        rows = recv.view(world, S * 32)[:, 32:32 + 4 * world].contiguous().view(torch.int32).to(torch.int64).cpu()
+        rows = rows & 0xffffffff                                      # (counts are unsigned 32-bit words)
+        tails = (rows - room).clamp_(min=0)                           # [sender][part]
+        send_counts = tails[rank].tolist()
+        recv_counts = tails[:, rank].tolist()
+        n_send, n_recv = sum(send_counts), sum(recv_counts)
+        if n_send * 32 > self._spill.numel():
+            raise RuntimeError("record exchange: the spill is smaller than the tails (%d records)" % n_send)
+        out = self._to_comm(self._spill[:n_send * 32])
+        got = torch.empty(max(n_recv, 1) * 32, dtype=torch.uint8, device=self.comm_device)
+        dist.all_to_all_single(got[:n_recv * 32], out, output_split_sizes=[x * 32 for x in recv_counts],
+                               input_split_sizes=[x * 32 for x in send_counts], group=self.group)
+        got = got if got.device == self.device else got.to(self.device)
+        if n_recv:
+            ex.records_adopt_more(n_recv, got.data_ptr())
+        self._tails = got                    # (kept until the next run: the adoption is queued, not finished)
 
     def _run_exact(self, ex, n_alignments_local=0):
         from . import _lib as L
@@ -541,7 +572,8 @@ class RecordExchanger:
 
 
 class SlotOverflow(Exception):
-    """A part did not fit its slot: scan the batch again and call RecordExchanger.run once more (the slots are larger now)."""
+    """Rounds 2-3: a part did not fit its slot and the caller scanned the batch again.  No longer raised (round 4: the tails
+    follow in a second all_to_all, RecordExchanger._exchange_tails); kept so that callers written against it still import."""
 
     def __init__(self, slot_records):
         super().__init__("record exchange: a part outgrew its slot; slots raised to %d records" % slot_records)

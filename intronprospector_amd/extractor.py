@@ -156,12 +156,19 @@ class JunctionsExtractor:
     def records_adopt(self, n, src_ptr, n_alignments=0):
         self._check(self.lib.ipx_records_adopt(self.h, n, src_ptr, n_alignments))
 
-    def records_partition_slots(self, splitters, slot_records, dst_ptr, error_order=(1 << 64) - 1, error_status=0):
+    def records_partition_slots(self, splitters, slot_records, dst_ptr, error_order=(1 << 64) - 1, error_status=0,
+                                spill_ptr=None, spill_records=0):
         """The pending records into len(splitters) + 1 slots of slot_records 32-byte records each (the first is the
-        slot's header) at dst_ptr (device); queued on the handle's stream, nothing read back."""
+        slot's header) at dst_ptr (device); queued on the handle's stream, nothing read back.  spill_ptr: device memory
+        for spill_records records -- what the slots cannot hold goes there, part after part (ipx.h)."""
         spl = np.ascontiguousarray(splitters, np.uint64)
-        self._check(self.lib.ipx_records_partition_slots(self.h, len(spl) + 1, spl.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                         int(slot_records), int(error_order), int(error_status), dst_ptr))
+        self._check(self.lib.ipx_records_partition_slots_spill(self.h, len(spl) + 1, spl.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                               int(slot_records), int(error_order), int(error_status), dst_ptr,
+                                                               spill_ptr, int(spill_records) if spill_ptr else 0))
+
+    def records_adopt_more(self, n, src_ptr):
+        """n more received records behind the pending ones (the tails of a slotted exchange that overflowed)"""
+        self._check(self.lib.ipx_records_adopt_more(self.h, int(n), src_ptr))
 
     def records_adopt_slots(self, n_slots, slot_records, src_ptr, n_alignments=0):
         """-> SlotsInfo: records adopted, the largest part any sender had, overflow, the earliest sender-side error"""

@@ -32,13 +32,9 @@ namespace {
 constexpr uint32_t LLB = 10, DB = 8;
 constexpr uint32_t LANE_WORDS = 1024;                 // private table space per lane: 4 KiB
 // byte offsets inside a lane's slice
-constexpr uint32_t O_LL = 0, O_D = 2048, O_SLL = 2560, O_SD = 3136, O_LENS = 3200, O_CNT = 3520;   // u16 ll[1024], u16 d[256], u16 sorted_ll[288], u16 sorted_d[32], u8 lens[320], u16 cnt_ll[16], u16 cnt_d[16]
+constexpr uint32_t O_LL = 0, O_SLL = 2560, O_SD = 3136, O_LENS = 3200, O_CNT = 3520;   // u16 ll[1024], (512 bytes that held the distance table until it moved to LDS), u16 sorted_ll[288], u16 sorted_d[32], u8 lens[320], u16 cnt_ll[16], u16 cnt_d[16]
 
-__constant__ uint16_t C_LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t C_LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t C_DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
-                                         4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t C_DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// (the length and distance codes' bases and extra-bit counts are computed, RFC 1951 3.2.5: see the symbol loop)
 __constant__ uint8_t C_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct Bits {
@@ -91,6 +87,15 @@ struct TabGlobal {
     uint16_t *p;
     __device__ __forceinline__ uint16_t get(uint32_t i) const { return p[i]; }
     __device__ __forceinline__ void set(uint32_t i, uint16_t v) const { p[i] = v; }
+};
+
+// the distance table (and the code-length code's, which is built in its space) in LDS, a column per lane: what a match
+// waits for is then one trip to memory less (round 4)
+struct TabLds {
+    uint16_t *p;                  // the lane's first entry
+    uint32_t stride;              // lanes per wave
+    __device__ __forceinline__ uint16_t get(uint32_t i) const { return p[i * stride]; }
+    __device__ __forceinline__ void set(uint32_t i, uint16_t v) const { p[i * stride] = v; }
 };
 
 // what the canonical walk needs of a code to go on BEHIND the direct table (round 4): the state of RFC 1951 3.2.2's count /
@@ -150,10 +155,18 @@ __device__ bool build(const uint8_t *lens, uint32_t n_sym, uint32_t primary, con
 
 // a symbol: through the direct table, or bit by bit (RFC 1951 3.2.2's canonical order); 0xffffffff: no such code
 // (lc != nullptr: the walk goes on behind the table, see LongCodes; primary >= 8)
+// (decode_entry: the table entry `e` of the next `primary` bits was fetched by the caller -- ahead of time, see the symbol loop)
+template <class Tab>
+__device__ __forceinline__ uint32_t decode_entry(Bits &b, const uint32_t e, uint32_t primary, const uint16_t *sorted, const uint16_t *cnt,
+                                                 const LongCodes *lc);
 template <class Tab>
 __device__ __forceinline__ uint32_t decode(Bits &b, const Tab tab, uint32_t primary, const uint16_t *sorted, const uint16_t *cnt,
                                            const LongCodes *lc = nullptr) {
-    const uint32_t e = tab.get(b.peek(primary));
+    return decode_entry<Tab>(b, tab.get(b.peek(primary)), primary, sorted, cnt, lc);
+}
+template <class Tab>
+__device__ __forceinline__ uint32_t decode_entry(Bits &b, const uint32_t e, uint32_t primary, const uint16_t *sorted, const uint16_t *cnt,
+                                                 const LongCodes *lc) {
     if (e != 0xffffu) {
         b.drop(e >> 12);
         return e & 0x1ffu;
@@ -233,16 +246,22 @@ struct OutBytes {
 
 // in_end == nullptr: block b's payload ends where block b + 1's begins (in_off has n_blocks + 1 entries)
 // order: the block a lane takes (null: its own number)
+// (no second launch bound: `__launch_bounds__(64, 3)` -- what the kernel's 162 registers give anyway -- crashes this
+// compiler's post-RA scheduler, ROCm 7.2.0 clang 22; the launcher asks the runtime how many waves fit)
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ in_off,
                                                      const uint64_t *__restrict__ in_end,
                                                      const uint32_t *__restrict__ isize, const uint64_t *__restrict__ out_off,
                                                      uint64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tables,
-                                                     uint32_t *__restrict__ status, const uint32_t *__restrict__ order) {
-    const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+                                                     uint32_t *__restrict__ status, const uint32_t *__restrict__ order,
+                                                     uint32_t lanes_per_wave) {
+    extern __shared__ uint16_t lds_d[];                                  // [256][lanes_per_wave]
+    if (threadIdx.x >= lanes_per_wave) return;
+    const uint64_t gid = (uint64_t)blockIdx.x * lanes_per_wave + threadIdx.x;
     if (gid >= n_blocks) return;
     const uint64_t blk = order ? order[gid] : gid;
     uint8_t *slice = reinterpret_cast<uint8_t *>(tables + blk * LANE_WORDS);
-    const TabGlobal ll{reinterpret_cast<uint16_t *>(slice + O_LL)}, dt{reinterpret_cast<uint16_t *>(slice + O_D)};
+    const TabGlobal ll{reinterpret_cast<uint16_t *>(slice + O_LL)};
+    const TabLds dt{lds_d + threadIdx.x, lanes_per_wave};
     uint16_t *sll = reinterpret_cast<uint16_t *>(slice + O_SLL), *sd = reinterpret_cast<uint16_t *>(slice + O_SD);
     uint8_t *lens = slice + O_LENS;
     uint16_t *cll = reinterpret_cast<uint16_t *>(slice + O_CNT), *cd = cll + 16;
@@ -253,6 +272,27 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     uint8_t *const o = ob.o;
     const uint32_t cap = isize[blk];
     uint32_t err = 0;
+    // A match of up to 32 bytes whose source lies wholly before its destination is copied in two halves (round 4): its
+    // source words are asked for when it is decoded, its bytes are stored when the NEXT match is decoded (or at the end)
+    // -- the symbols between do not wait for the copy's trip to memory.  Memory sees the lane's loads and stores in program
+    // order, so a later match that reads these bytes finds them: the stores below are issued before its loads.
+    uint32_t p_len = 0, p_at = 0;
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    auto put_word = [&](uint32_t k, unsigned long long w) {
+        const uint32_t rem = p_len - 8u * k;                              // bytes of the match from this word on
+        uint8_t *d = o + p_at + 8u * k;
+        if (rem >= 8u) reinterpret_cast<U64 *>(d)->v = w;
+        else for (uint32_t j = 0; j < rem; ++j) d[j] = (uint8_t)(w >> (8u * j));
+    };
+    auto retire = [&]() {
+        if (p_len) {
+            put_word(0, p0);
+            if (p_len > 8u) put_word(1, p1);
+            if (p_len > 16u) put_word(2, p2);
+            if (p_len > 24u) put_word(3, p3);
+            p_len = 0;
+        }
+    };
     for (uint32_t guard = 0; guard < 70000 && !err; ++guard) {            // a block of n bytes has at most n / 1 DEFLATE blocks worth looking at
         b.fill();
         const uint32_t final_block = b.take(1), type = b.take(2);
@@ -315,26 +355,54 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 if (!build(lens + hlit, hdist, DB, dt, sd, cd, &lc_d)) { err = 2; break; }
                 if (!build(lens, hlit, LLB, ll, sll, cll, &lc_ll)) { err = 2; break; }
             }
-            // symbols
+            // symbols.  A lane's turn is a chain of dependent round trips to memory, and the wave's turn is its slowest lane's
+            // -- in practice a match's, some lane of 64 has one every turn: table entry of the length code, base and extra
+            // bits of that length (tables), entry of the distance code, its base and extra bits, the bytes to copy: five
+            // trips, ~5 us.  Round 4, second half: lengths and distances come from their codes by arithmetic (RFC 1951
+            // 3.2.5's tables are geometric: no load), and the entry of the NEXT symbol is asked for as soon as the bits of
+            // this one are known to be spent -- before the copy, whose source bytes then travel at the same time: a match
+            // is the distance entry and the copy's bytes behind one another, a literal one entry.
             bool eob = false;
+            b.fill();
+            uint32_t e_next = ll.get(b.peek(LLB));
             for (uint32_t sguard = 0; sguard < 70000; ++sguard) {        // every symbol but the last writes a byte
-                b.fill();
-                const uint32_t sym = decode(b, ll, LLB, sll, cll, &lc_ll);
+                const uint32_t sym = decode_entry<TabGlobal>(b, e_next, LLB, sll, cll, &lc_ll);
                 if (sym < 256) {
                     if (ob.n >= cap) { err = 5; break; }
+                    b.fill();
+                    e_next = ll.get(b.peek(LLB));
                     ob.put(sym);
                     continue;
                 }
                 if (sym == 256) { eob = true; break; }
                 if (sym > 285) { err = 3; break; }
-                const uint32_t len = C_LEN_BASE[sym - 257] + b.take(C_LEN_EXTRA[sym - 257]);
+                // 257..264: 3..10; then four codes per extra bit count; 285: 258
+                const uint32_t li = sym - 257u;
+                const uint32_t lx = (li < 8u || li == 28u) ? 0u : (li >> 2) - 1u;
+                const uint32_t lbase = li < 8u ? 3u + li : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << lx));
+                const uint32_t len = lbase + b.take(lx);
                 b.fill();
                 const uint32_t ds = decode(b, dt, DB, sd, cd, &lc_d);
                 if (ds > 29) { err = 3; break; }
-                const uint32_t dist = C_DIST_BASE[ds] + b.take(C_DIST_EXTRA[ds]);
+                // 0..3: 1..4; then two codes per extra bit count
+                const uint32_t dx = ds < 4u ? 0u : (ds >> 1) - 1u;
+                const uint32_t dbase = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
+                const uint32_t dist = dbase + b.take(dx);
                 if (dist > ob.n) { err = 4; break; }
                 if (ob.n + len > cap) { err = 5; break; }
+                b.fill();
+                e_next = ll.get(b.peek(LLB));                            // on its way while the match is copied
+                retire();                                                // the match before this one: its bytes go to memory now
                 ob.flush();                                              // the match reads what was produced so far from memory
+                if (len <= 32u && dist >= len) {
+                    // (all four words: what lies behind the source's last byte is not used -- and readable, the output
+                    // buffer ends in spare bytes)
+                    const U64 *src = reinterpret_cast<const U64 *>(o + ob.n - dist);
+                    p0 = src[0].v; p1 = src[1].v; p2 = src[2].v; p3 = src[3].v;
+                    p_len = len; p_at = ob.n;
+                    ob.after_copy(len);
+                    continue;
+                }
                 // 8-byte words (unaligned: the hardware takes them) where a word's source ends before its destination begins;
                 // 32 bytes a turn, all four loads before the four stores, where that holds for the whole piece.  (Byte by
                 // byte every load waits for the store before it: ~1 us per byte; and the wave waits for its slowest lane.)
@@ -383,6 +451,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         }
         if (final_block || err) break;
     }
+    retire();
     ob.flush();
     if (!err && b.past * 8 > b.cnt) err = 6;                            // bits were taken from beyond the block's end
     if (!err && ob.n != cap) err = 7;
@@ -462,8 +531,23 @@ size_t ipx_bgzf_tables_bytes(uint64_t n_blocks) { return (size_t)4 * LANE_WORDS 
 static void launch_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end, const uint32_t *isize,
                            const uint64_t *out_off, uint64_t n_blocks, uint8_t *out, uint32_t *tables, uint32_t *status,
                            const uint32_t *order) {
-    const dim3 grid((uint32_t)ipx_div_up(n_blocks, 64));
-    hipLaunchKernelGGL(k_bgzf_inflate, grid, dim3(64), 0, s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status, order);
+    // Lanes per wave: as few as still let EVERY wave be resident at once (three per SIMD by the kernel's registers).  A wave's turn lasts as long as its slowest lane's, so fewer lanes per wave wait less for each other and
+    // more waves overlap their trips to memory -- until the waves no longer fit the chip and run in rounds (measured on
+    // 36 316 blocks: 64 lanes 101 ms, 32: 91, 16: 81, 12: 74 = 3027 waves on 3072 places; 8: a second round).
+    static const uint32_t places = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate, 64, 16 * 512) != hipSuccess || per_cu <= 0) per_cu = 12;
+        (void)hipGetLastError();
+        return (uint32_t)cus * (uint32_t)per_cu;
+    }();
+    const char *e = getenv("IPX_INFLATE_LPW");                            // (experiments)
+    uint32_t lpw = e ? (uint32_t)atoi(e) : (uint32_t)ipx_div_up(n_blocks, places - places / 64);
+    if (lpw < 1) lpw = 1;
+    if (lpw > 64) lpw = 64;
+    const dim3 grid((uint32_t)ipx_div_up(n_blocks, lpw));
+    hipLaunchKernelGGL(k_bgzf_inflate, grid, dim3(64), (size_t)lpw * 512, s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status, order, lpw);
 }
 
 hipError_t ipx_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end,

@@ -10,6 +10,7 @@
 #include "ipx_reduce.h"
 
 #include <algorithm>
+#include <chrono>
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
@@ -1663,6 +1664,16 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > have && need - have > (uint64_t)((double)free_b * 0.9))
             return fail(h, IPX_ENOMEM, "ipx_decode_bgzf: the file needs about %s%ld MB of device memory", "", (long)(need >> 20));
     }
+    // IPX_DEBUG_PLAN: where the call's time goes (every lap waits for the stream: the sums are longer than the call)
+    const bool laps = getenv("IPX_DEBUG_PLAN") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!laps) return;
+        (void)hipStreamSynchronize(h->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "ipx_decode_bgzf: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if ((rc = ensure(h, h->bz_comp, f->n_bytes + 16))) return rc;
     if ((rc = ensure(h, h->bz_out, T + 64))) return rc;
     if ((rc = ensure(h, h->bz_tab, t_total + 256))) return rc;
@@ -1688,7 +1699,9 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
         else
             (void)hipGetLastError();
     }
+    lap("device memory, pinning");
     HIPCHK(hipMemcpyAsync(h->bz_comp.p, f->bytes, f->n_bytes, hipMemcpyHostToDevice, s));
+    lap("the file's bytes to the device");
     HIPCHK(hipMemsetAsync(h->bz_comp.as<char>() + f->n_bytes, 0, 16, s));
     HIPCHK(hipMemsetAsync(h->bz_out.as<char>() + T, 0, 64, s));
     HIPCHK(hipMemcpyAsync(tb + t_pb, f->payload_begin, 8 * nb, hipMemcpyHostToDevice, s));
@@ -1710,6 +1723,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     HIPCHK(ipx_launch_bgzf_inflate(s, h->bz_comp.as<uint8_t>(), (const uint64_t *)(tb + t_pb), (const uint64_t *)(tb + t_pe),
                                    (const uint32_t *)(tb + t_is), (const uint64_t *)(tb + t_oo), (const uint32_t *)(tb + t_crc), nb,
                                    h->bz_out.as<uint8_t>(), h->bz_ws.as<uint32_t>(), status, (const uint32_t *)(tb + t_ord)));
+    lap("tables, inflate, CRC-32");
     // flags[0] = unaligned, flags[1] = first bad block + 1 (inflate status or CRC), flags[2] = records in all
     HIPCHK(ipx_launch_bam_count_blocks(s, h->bz_out.as<uint8_t>(), (const uint64_t *)(tb + t_oo), (const uint32_t *)(tb + t_is), nb,
                                        f->records_begin, (uint32_t *)(tb + t_cnt), (uint32_t *)(tb + t_pre), (uint32_t *)(tb + t_sums),
@@ -1717,6 +1731,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     hipLaunchKernelGGL(k_first_bad_block, dim3((uint32_t)ipx_div_up(nb, 256)), dim3(256), 0, s, status, (uint32_t)nb, flags + 1);
     HIPCHK(hipGetLastError());
     if ((rc = read_back(h, h->pin_small, flags, 4))) return rc;
+    lap("records per block");
     const uint32_t *fl = (const uint32_t *)h->pin_small;
     if (fl[1]) {
         uint32_t st = 0;
@@ -1741,6 +1756,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
                                             (uint8_t *)(sa + o_nh), (uint32_t *)(sa + o_off), (uint32_t *)(sa + o_nc), h->bam_raw.p, bam_err,
                                             &total_dev));
         if ((rc = read_back(h, h->pin_small, bam_err, 1, total_dev, 1))) return rc;
+        lap("record fields");
         const uint32_t *r2 = (const uint32_t *)h->pin_small;
         if (r2[0] != 0xffffffffu)
             return fail(h, IPX_EINVAL, "ipx_decode_bgzf: malformed BAM record%s (alignment %ld)", "", (long)r2[0] - 1);
@@ -1749,6 +1765,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
         HIPCHK(ipx_launch_bam_decode_cigar(s, h->bz_out.as<uint8_t>(), n, nw, (const uint32_t *)(sa + o_off), (const uint32_t *)(sa + o_nc),
                                            h->bz_cigar.as<uint32_t>(), h->bam_raw.p, bam_err));
         if ((rc = read_back(h, h->pin_small, bam_err, 1))) return rc;
+        lap("CIGAR words");
         if (((const uint32_t *)h->pin_small)[0] != 0xffffffffu)
             return fail(h, IPX_EINVAL, "ipx_decode_bgzf: CIGAR lengths and records disagree%s%ld", "", 0);
         out->n_cigar_words = nw;

@@ -86,7 +86,7 @@ static void print_anchor_bed_row(const Junction &j, std::ostream &out) {
     out << "\t" << read_count_to_bed_score(j.total_read_count()) << "\t" << j.strand << "\t" << j.anchor_start
         << "\t" << j.anchor_end << "\t" << bed_color(j.splice_sites) << "\t" << 2 << "\t"
         << (uint32_t)(j.intron_start - j.anchor_start) << "," << (uint32_t)(j.anchor_end - j.intron_end) << "\t"
-        << "0," << (uint32_t)(j.intron_end - j.anchor_start) << std::endl;
+        << "0," << (uint32_t)(j.intron_end - j.anchor_start) << '\n';
 }
 
 // src/junctions.cc:204-217
@@ -95,7 +95,7 @@ static void print_intron_bed_row(const Junction &j, int columns, std::ostream &o
     print_name(j, out);
     out << "\t" << read_count_to_bed_score(j.total_read_count()) << "\t" << j.strand;
     if (columns == 9) out << "\t" << j.intron_start << "\t" << j.intron_end << "\t" << bed_color(j.splice_sites);
-    out << std::endl;
+    out << '\n';
 }
 
 // src/junctions.cc:220-225
@@ -104,17 +104,23 @@ static void print_call_row(const Junction &j, std::ostream &out) {
         << j.read_counts[SINGLE_MAPPED_READ] << "\t" << j.read_counts[MULTI_MAPPED_READ] << "\t"
         << j.read_counts[UNSURE_READ] << "\t" << (uint32_t)(j.intron_start - j.anchor_start) << "\t"
         << (uint32_t)(j.anchor_end - j.intron_end) << "\t" << j.confidence << "\t" << j.splice_sites << "\tsj"
-        << j.ijunc << std::endl;
+        << j.ijunc << '\n';
 }
 
+// The reference ends every row with std::endl, i.e. a flush and a write() per row (src/junctions.cc:199,216,224): 200 000
+// system calls per file, a tenth of a second of the command line once the device does the rest.  The bytes are the same
+// with '\n' and ONE flush when a target's rows are out -- what a reader of the file can tell apart is only how much of an
+// unfinished target's rows a crash leaves behind.
 void print_anchor_bed(const JunctionVector &juncs, float min_confidence_score, std::ostream &out) {
     for (const Junction &j : juncs)
         if (j.confidence >= min_confidence_score) print_anchor_bed_row(j, out);
+    out.flush();
 }
 
 void print_intron_bed(const JunctionVector &juncs, float min_confidence_score, int columns, std::ostream &out) {
     for (const Junction &j : juncs)
         if (j.confidence >= min_confidence_score) print_intron_bed_row(j, columns, out);
+    out.flush();
 }
 
 void print_junction_call_header(std::ostream &out) {
@@ -127,6 +133,7 @@ void print_intron_call_tsv(const JunctionVector &juncs, float min_confidence_sco
     out.precision(3);
     for (const Junction &j : juncs)
         if (j.confidence >= min_confidence_score) print_call_row(j, out);
+    out.flush();
 }
 
 }  // namespace ipxhost

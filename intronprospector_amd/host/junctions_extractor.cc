@@ -135,6 +135,7 @@ JunctionsExtractor::~JunctionsExtractor() {
         if (b.mem) ipx_host_free(b.mem);
         if (b.raw) ipx_host_free(b.raw);
     }
+    if (timeline_) fprintf(stderr, "ipx_timeline: extractor gone %.3f s after it was made\n", now_s() - t_born_);
 }
 
 // (re)allocate a batch's pinned byte buffer for BAM records; what it holds is kept
@@ -452,6 +453,7 @@ bool JunctionsExtractor::try_device_file() {
     const double t0 = timeline_ ? now_s() : 0.0;
     struct Drop { FileLoad &f; ~Drop() { f.drop(); } } drop{file_load_};
     if (!file_load_.wait()) return false;
+    if (timeline_) fprintf(stderr, "ipx_timeline: waited %.3f s for the file's bytes\n", now_s() - t0);
     const size_t size = file_load_.size;
     // the block headers (SAM spec 4.1: gzip member with a BC extra subfield that holds BSIZE - 1)
     const uint8_t *d = file_load_.buf;
@@ -490,7 +492,9 @@ bool JunctionsExtractor::try_device_file() {
     f.records_begin = 4 + reader_->raw_header().size();          // magic, then what raw_header() holds: l_text ... the references
     f.tid_map = canon_tid_.data();
     f.n_tid_map = (uint32_t)canon_tid_.size();
+    const double t1 = timeline_ ? now_s() : 0.0;
     if (ipx_decode_bgzf(h_, &f, &dev_batch_) != IPX_OK) return false;
+    if (timeline_) fprintf(stderr, "ipx_timeline: block headers + device %.3f s, ipx_decode_bgzf %.3f s\n", t1 - t0, now_s() - t1);
     dev_tid_.resize(dev_batch_.n_alignments);
     if (!dev_tid_.empty() && ipx_copy(h_, dev_tid_.data(), dev_batch_.tid, dev_tid_.size() * sizeof(int32_t)) != IPX_OK) return false;
     dev_cursor_ = 0;

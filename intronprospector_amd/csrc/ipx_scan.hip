@@ -1202,6 +1202,41 @@ __device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
 // passed a LATER barrier -- i.e. there is a barrier between the last write and the read, and one between the read and
 // the next write.  (c) is the one that was violated: pool_n was read for the early-combine test while faster threads
 // already added the next round's records to it.
+// k_scan_short's argument block as the ABI lays it out (kernarg segment; every member naturally aligned).  The kernel
+// holds more uniform values than a wave has scalar registers (121 were spilled to lanes of vector registers and read back
+// with v_readlane, the most frequent instruction of the kernel): what a tile needs only once, at its copy-out, is read from
+// here at that point instead of being kept (fresh_args: the empty asm makes the pointer opaque, so the loads stay where
+// they are written).
+struct ShortArgs {
+    ScanParams p;
+    uint64_t n, n_words, base_read_index;
+    const int32_t *a_tid, *a_pos;
+    const uint16_t *a_flag;
+    const uint8_t *a_xs, *a_nh;
+    const uint32_t *a_off, *a_nc, *cigar, *tail, *rank_of_tid;
+    uint4 *items, *pays;
+    uint32_t *cnts;
+    uint8_t *digs;
+    uint64_t capacity;
+    Counters *counters;
+    uint32_t *defer;
+};
+static_assert(offsetof(ShortArgs, n) == sizeof(ScanParams) && offsetof(ShortArgs, a_tid) == sizeof(ScanParams) + 24 &&
+              offsetof(ShortArgs, defer) == sizeof(ScanParams) + 152, "ShortArgs must mirror k_scan_short's parameter list");
+typedef const __attribute__((address_space(4))) ShortArgs *ShortArgsPtr;
+// (a struct out of the argument block: member by member, the copy constructor does not take the constant address space)
+template <class T>
+__device__ __forceinline__ T load_arg(const __attribute__((address_space(4))) T *src) {
+    T v;
+    __builtin_memcpy(&v, src, sizeof(T));
+    return v;
+}
+__device__ __forceinline__ ShortArgsPtr fresh_args() {
+    ShortArgsPtr k = (ShortArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 template <uint32_t RPT, uint32_t POOL, uint32_t BT>
 __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                                     const int32_t *__restrict__ a_tid,
@@ -1248,9 +1283,11 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         return __shfl(base, first) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     };
 
-    const AlnArrays aln{a_tid, a_pos, a_flag, a_xs, a_nh, a_off, a_nc, rank_of_tid, n, n_words, base_read_index};
-    auto load_ctx = [&](uint64_t i, ReadCtx &c, uint32_t &nc, uint32_t &off, unsigned long long &err) {
-        load_read_ctx(p, aln, i, c, nc, off, err);
+    // (the batch's arrays: read from the argument block where a tile or a walk pass begins, see ShortArgs)
+    auto fresh_aln = [&]() {
+        const ShortArgsPtr ka = fresh_args();
+        return AlnArrays{ka->a_tid, ka->a_pos, ka->a_flag, ka->a_xs, ka->a_nh, ka->a_off, ka->a_nc, ka->rank_of_tid,
+                         ka->n, ka->n_words, ka->base_read_index};
     };
 
     IPX_ST_DECL;
@@ -1261,6 +1298,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     // and the branches that hold barriers test nothing else: `if (recombine)`, `if (!final_pass)`; the per-round
     // `if (r * BT >= total) continue` skips no barrier)
     auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
+        const ScanParams cp = load_arg(&fresh_args()->p);             // (what the combiner needs of the parameters, read here: see ShortArgs)
         for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
         __syncthreads();
         // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
@@ -1376,11 +1414,11 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             pass_r[r] = true;
             never_r[r] = false;
             if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
-            if (p.combine == 2u && k < total) {
+            if (cp.combine == 2u && k < total) {
                 const uint4 it = pool_item[k];
                 const uint32_t px = pool_pay[k].x;
-                const KeyParts kp = unpack_key(it, p.key);
-                const uint32_t m = ipx_motif_of(p.genome, p.skip_missing, kp.rank, kp.start, kp.end);
+                const KeyParts kp = unpack_key(it, cp.key);
+                const uint32_t m = ipx_motif_of(cp.genome, cp.skip_missing, kp.rank, kp.start, kp.end);
                 pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
                 // Splice sites that are canonical on NEITHER strand: no record of this junction passes the filter whatever
                 // its strand, so the junction is never created and none of its records is ever counted (add_junction,
@@ -1470,8 +1508,24 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             __syncthreads();
             return;
         }
+        // (where the records go: read from the argument block here, see ShortArgs)
+        const ShortArgsPtr ka = fresh_args();
+        const uint32_t ka_stripes = ka->p.n_stripes;
+        const uint64_t ka_base = ka->p.base, ka_capacity = ka->capacity;
+        const DigitSpec ka_first = load_arg(&ka->p.first);
+        uint4 *const ka_items = ka->items, *const ka_pays = ka->pays;
+        uint32_t *const ka_cnts = ka->cnts;
+        uint8_t *const ka_digs = ka->digs;
+        auto index_of = [&](uint64_t i) -> uint64_t {                      // append_index
+            if (!ka_stripes) return i;
+            const uint64_t chunk = (i >> IPX_STRIPE_CHUNK_BITS) * IPX_STRIPES + stripe;
+            return ka_base + ((chunk << IPX_STRIPE_CHUNK_BITS) | (i & ((1u << IPX_STRIPE_CHUNK_BITS) - 1)));
+        };
         if (t == 0) {
-            tile_slot = n_out ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)n_out) : 0ull;
+            Counters *const ka_counters = ka->counters;
+            unsigned long long *ctr = ka_stripes ? reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ka_counters) + IPX_CNT_STRIPE0 + 128 * stripe)
+                                                 : &ka_counters->n_records;
+            tile_slot = n_out ? atomicAdd(ctr, (unsigned long long)n_out) : 0ull;
             merged_acc += total - n_out;
         }
         __syncthreads();
@@ -1479,14 +1533,14 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 #pragma unroll
         for (uint32_t r = 0; r < CR; ++r) {
             const uint32_t k = r * BT + t;
-            const uint64_t idx = append_index(p, stripe, slot + pos_r[r]);
-            if (live_r[r] && idx < capacity) {
+            const uint64_t idx = index_of(slot + pos_r[r]);
+            if (live_r[r] && idx < ka_capacity) {
                 uint4 it = pool_item[k];
-                cnts[idx] = it.w;
+                ka_cnts[idx] = it.w;
                 it.w = (uint32_t)idx;
-                items[idx] = it;
-                pays[idx] = pool_pay[k];
-                digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                ka_items[idx] = it;
+                ka_pays[idx] = pool_pay[k];
+                ka_digs[idx] = (uint8_t)ipx_digit_of(it, ka_first);
                 kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                 kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
             }
@@ -1496,19 +1550,25 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
     // the tile's records -> record arrays (total <= POOL)
     auto store_pool = [&](const uint32_t total, const uint32_t comb, const bool recombined) {
         if (!comb) {                                       // (uniform: a kernel argument masked with the tile number)
-            if (t == 0) tile_slot = total ? atomicAdd(append_counter(counters, p, stripe), (unsigned long long)total) : 0ull;
+            const ShortArgsPtr ka = fresh_args();
+            const ScanParams kp = load_arg(&ka->p);
+            uint4 *const ka_items = ka->items, *const ka_pays = ka->pays;
+            uint32_t *const ka_cnts = ka->cnts;
+            uint8_t *const ka_digs = ka->digs;
+            const uint64_t ka_capacity = ka->capacity;
+            if (t == 0) tile_slot = total ? atomicAdd(append_counter(ka->counters, kp, stripe), (unsigned long long)total) : 0ull;
             __syncthreads();
             const uint64_t slot = tile_slot;
             for (uint32_t k = t; k < total; k += BT) {
-                const uint64_t idx = append_index(p, stripe, slot + k);
-                if (idx < capacity) {
+                const uint64_t idx = append_index(kp, stripe, slot + k);
+                if (idx < ka_capacity) {
                     uint4 it = pool_item[k];
                     it.w = (uint32_t)idx;
-                    items[idx] = it;
+                    ka_items[idx] = it;
                     const uint4 py = pool_pay[k];
-                    pays[idx] = py;
-                    cnts[idx] = IPX_CNT_ONE(py.x & 3u);
-                    digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                    ka_pays[idx] = py;
+                    ka_cnts[idx] = IPX_CNT_ONE(py.x & 3u);
+                    ka_digs[idx] = (uint8_t)ipx_digit_of(it, kp.first);
                     kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                     kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
                 }
@@ -1542,6 +1602,10 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         uint4 wb_r[RPT];
         bool walk_r[RPT];
         uint4 w3_r[RPT];
+        const AlnArrays aln = fresh_aln();
+        const ScanParams tp = load_arg(&fresh_args()->p);
+        const uint32_t *const cigar_ = fresh_args()->cigar, *const tail_ = fresh_args()->tail;
+        const uint64_t n_words_ = aln.n_words;
         {
             RawAln raw_r[RPT];
             uint32_t rank_r[RPT];
@@ -1554,18 +1618,18 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             for (uint32_t r = 0; r < RPT; ++r) pin_raw(raw_r[r]);
 #pragma unroll
             for (uint32_t r = 0; r < RPT; ++r)
-                rank_r[r] = (!p.rank_is_tid && p.n_targets) ? rank_of_tid[rank_index(p, raw_r[r])] : (uint32_t)raw_r[r].tid;
+                rank_r[r] = (!tp.rank_is_tid && tp.n_targets) ? aln.rank_of_tid[rank_index(tp, raw_r[r])] : (uint32_t)raw_r[r].tid;
 #pragma unroll
             for (uint32_t r = 0; r < RPT; ++r)
-                read_ctx_of(p, aln, tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, raw_r[r], rank_r[r], c_r[r], nc_r[r], off_r[r], my_err);
+                read_ctx_of(tp, aln, tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, raw_r[r], rank_r[r], c_r[r], nc_r[r], off_r[r], my_err);
         }
         IPX_ST_LAP(0);                      // attributes arrived (the loads' issue + first use)
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
-            w3_r[r] = load_cigar4(cigar, tail, n_words, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
+            w3_r[r] = load_cigar4(cigar_, tail_, n_words_, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
             // (words 4..7 of the CIGARs that have them -- off + nc <= n_words was checked --, else the array's first: every
             // lane loads, a load behind a branch is waited for at the branch's end)
-            wb_r[r] = load_cigar4(cigar, tail, n_words, (nc_r[r] >= 5 && nc_r[r] <= 7) ? (uint64_t)off_r[r] + 4 : 0ull);
+            wb_r[r] = load_cigar4(cigar_, tail_, n_words_, (nc_r[r] >= 5 && nc_r[r] <= 7) ? (uint64_t)off_r[r] + 4 : 0ull);
         }
 #pragma unroll
         for (uint32_t r = 0; r < RPT; ++r) {
@@ -1608,20 +1672,22 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             if (dm) {
                 const int first = __ffsll(dm) - 1;
                 uint32_t base = 0;
-                if ((int)lane == first) base = atomicAdd(defer_counter(counters), (uint32_t)__popcll(dm));
+                const ShortArgsPtr ka = fresh_args();
+                uint32_t *const ka_defer = ka->defer;
+                if ((int)lane == first) base = atomicAdd(defer_counter(ka->counters), (uint32_t)__popcll(dm));
                 base = __shfl(base, first);
                 if (rest_it)
-                    defer[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] =
+                    ka_defer[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] =
                         (uint32_t)(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t);
             }
             // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, then either finish(): one record, or N: the record,
             // its right anchor becomes the next left anchor, -> INTRON, M: -> RIGHT, finish(): the second record
             // (junctions_extractor.cc:208-254,278-282).  Five lengths below 2^28 cannot leave 32 bits.
             const uint32_t a = e0 >> 4, n1 = e1 >> 4, b = e2 >> 4, n2 = e3 >> 4, c5 = e4 >> 4;
-            const bool pass1 = (plain || two) && !c.read_rejected && n1 >= p.min_intron_length && n1 <= p.max_intron_length &&
-                               a >= p.min_anchor_length && b >= p.min_anchor_length;     // junction_qc :392-397
-            const bool pass2 = two && !c.read_rejected && n2 >= p.min_intron_length && n2 <= p.max_intron_length &&
-                               b >= p.min_anchor_length && c5 >= p.min_anchor_length;
+            const bool pass1 = (plain || two) && !c.read_rejected && n1 >= tp.min_intron_length && n1 <= tp.max_intron_length &&
+                               a >= tp.min_anchor_length && b >= tp.min_anchor_length;     // junction_qc :392-397
+            const bool pass2 = two && !c.read_rejected && n2 >= tp.min_intron_length && n2 <= tp.max_intron_length &&
+                               b >= tp.min_anchor_length && c5 >= tp.min_anchor_length;
             const unsigned long long em1 = ipx_ballot(pass1);
             if (em1) {
                 const uint32_t slot = pool_slot(em1);
@@ -1630,7 +1696,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     cc.pos = 0;
                     uint4 it, pay;
                     const Rec rr{0, (int64_t)a, (int64_t)(a + n1), (int64_t)(a + n1 + b), 0, 0, 0, 0};
-                    pack_record_rel(p, cc, rr, (uint32_t)c.pos, 0u, it, pay);
+                    pack_record_rel(tp, cc, rr, (uint32_t)c.pos, 0u, it, pay);
                     pool_item[slot] = it;
                     pool_pay[slot] = pay;
                 }
@@ -1644,7 +1710,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     uint4 it, pay;
                     const uint32_t s2 = a + n1 + b;
                     const Rec rr{(int64_t)(a + n1), (int64_t)s2, (int64_t)(s2 + n2), (int64_t)(s2 + n2 + c5), 0, 0, 0, 0};
-                    pack_record_rel(p, cc, rr, (uint32_t)c.pos, pass1 ? 1u : 0u, it, pay);      // ordinals count QC-passed records
+                    pack_record_rel(tp, cc, rr, (uint32_t)c.pos, pass1 ? 1u : 0u, it, pay);      // ordinals count QC-passed records
                     pool_item[slot] = it;
                     pool_pay[slot] = pay;
                 }
@@ -1688,6 +1754,10 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 // than 8 ops are on its list already, those that wait for a walk pass stay where they are).  A walk
                 // pass cannot overflow (see "the walks"); if it ever did, its alignments would go the same way.
                 const uint64_t tile_base = tile * ((uint64_t)BT * RPT);
+                const ShortArgsPtr ka = fresh_args();
+                const uint32_t *const a_nc_ = ka->a_nc;
+                uint32_t *const ka_defer = ka->defer;
+                const uint64_t n_ = ka->n;
                 uint32_t mine_n = 0;
                 if (from_walk) {
                     mine_n = t < w_take ? 1u : 0u;
@@ -1695,7 +1765,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
 #pragma unroll
                     for (uint32_t r = 0; r < RPT; ++r) {
                         const uint64_t i = tile_base + (uint64_t)r * BT + t;
-                        mine_n += (i < n && !walk_r[r] && a_nc[i] <= 8) ? 1u : 0u;
+                        mine_n += (i < n_ && !walk_r[r] && a_nc_[i] <= 8) ? 1u : 0u;
                     }
                 }
                 // block-wide exclusive prefix of mine_n (NW waves)
@@ -1709,16 +1779,16 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                 __syncthreads();
                 uint32_t before = 0, all = 0;
                 for (uint32_t w = 0; w < NW; ++w) { const uint32_t sw = kb_s[w][0]; if (w < wave) before += sw; all += sw; }
-                if (t == 0) tile_slot = all ? atomicAdd(defer_counter(counters), all) : 0u;
+                if (t == 0) tile_slot = all ? atomicAdd(defer_counter(ka->counters), all) : 0u;
                 __syncthreads();
                 uint32_t at = (uint32_t)tile_slot + before + incl - mine_n;
                 if (from_walk) {
-                    if (t < w_take) defer[at] = dx_list[w_from + t];
+                    if (t < w_take) ka_defer[at] = dx_list[w_from + t];
                 } else {
 #pragma unroll
                     for (uint32_t r = 0; r < RPT; ++r) {
                         const uint64_t i = tile_base + (uint64_t)r * BT + t;
-                        if (i < n && !walk_r[r] && a_nc[i] <= 8) defer[at++] = (uint32_t)i;
+                        if (i < n_ && !walk_r[r] && a_nc_[i] <= 8) ka_defer[at++] = (uint32_t)i;
                     }
                 }
             }
@@ -1742,12 +1812,15 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     ReadCtx c;
                     uint32_t nc = 0, off = 0;
                     unsigned long long seen = IPX_ERRW_NONE;     // gate errors were reported when the alignment was listed
-                    load_ctx(i, c, nc, off, seen);
+                    const AlnArrays waln = fresh_aln();
+                    const ScanParams wp = load_arg(&fresh_args()->p);
+                    const uint32_t *const wcigar = fresh_args()->cigar, *const wtail = fresh_args()->tail;
+                    load_read_ctx(wp, waln, i, c, nc, off, seen);
                     if (!mine) nc = 0;
                     const bool small = nc != 0 && nc <= 8;
-                    const uint4 wa = load_cigar4(cigar, tail, n_words, small ? (uint64_t)off : 0ull);
+                    const uint4 wa = load_cigar4(wcigar, wtail, waln.n_words, small ? (uint64_t)off : 0ull);
                     // (a lane without a CIGAR of five to eight words reads the array's first words)
-                    const uint4 wb = load_cigar4(cigar, tail, n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
+                    const uint4 wb = load_cigar4(wcigar, wtail, waln.n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
                 const uint32_t pos32 = (uint32_t)c.pos;
 
                 bool active = small, pending = false, fin = false;
@@ -1761,9 +1834,9 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
                     const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
                     const uint32_t ilen = q_ie - q_is;
-                    return !c.read_rejected && ilen >= p.min_intron_length && ilen <= p.max_intron_length &&
-                           (uint64_t)(q_is - q_as) >= (uint64_t)q_l + p.min_anchor_length &&
-                           (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + p.min_anchor_length;
+                    return !c.read_rejected && ilen >= wp.min_intron_length && ilen <= wp.max_intron_length &&
+                           (uint64_t)(q_is - q_as) >= (uint64_t)q_l + wp.min_anchor_length &&
+                           (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + wp.min_anchor_length;
                 };
                 // QC, pack and store the waiting snapshots of the whole wave
                 auto drain = [&]() {
@@ -1778,7 +1851,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                                 uint4 it, pay;
                                 const Rec rr{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
                                              (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
-                                pack_record_rel(p, cc, rr, pos32, ordinal, it, pay);
+                                pack_record_rel(wp, cc, rr, pos32, ordinal, it, pay);
                                 pool_item[slot] = it;
                                 pool_pay[slot] = pay;
                             }
@@ -1797,7 +1870,7 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
                     lind += (c_id && in_l) ? len : 0u;
                     rind += (c_id && in_r) ? len : 0u;
                     const uint32_t indel2 = cur_indel + len;
-                    const bool over = c_id && indel2 > p.max_anchor_indel_size;
+                    const bool over = c_id && indel2 > wp.max_anchor_indel_size;
                     const bool trig = in_r && (c_n || c_sh || over);
                     const bool last = run && left == 1;
                     if (ipx_ballot(pending && (trig || last))) drain();
@@ -1863,15 +1936,16 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
             const unsigned long long o = __shfl_xor(e, d);
             e = o < e ? o : e;
         }
-        if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+        if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&fresh_args()->counters->err_word, e);
     }
 #ifdef IPX_SCAN_STATS
     if (t == 0 && (blockIdx.x % 199) == 0 && st_tiles)
         printf("block %u: %u tiles; cycles per tile: attributes %llu, phase 1 %llu, walks %llu, combine + copy-out %llu\n", blockIdx.x,
                st_tiles, st_ph[0] / st_tiles, st_ph[1] / st_tiles, st_ph[2] / st_tiles, st_ph[3] / st_tiles);
 #endif
+    Counters *const counters_ = fresh_args()->counters;
     if (t == 0 && merged_acc)
-        atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED), merged_acc);
+        atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters_) + IPX_CNT_MERGED), merged_acc);
     uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -1886,9 +1960,9 @@ __global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, 
         uint32_t o = 0, a = ~0u;
         for (uint32_t w = 0; w < NW; ++w) { o |= kb_s[w][t]; a &= kb_s[w][t]; }
         if (t < 3) {
-            if (o) atomicOr(&counters->key_or[t], o);
+            if (o) atomicOr(&counters_->key_or[t], o);
         } else {
-            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+            if (a != ~0u) atomicAnd(&counters_->key_and[t - 3], a);
         }
     }
 }

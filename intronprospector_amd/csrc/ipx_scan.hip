@@ -645,6 +645,38 @@ constexpr uint32_t LONG3_RINGW = 32;         // CIGAR words per lane in the LDS 
 constexpr uint32_t LONG3_DRAIN = 40;         // waiting snapshots that trigger a drain
 constexpr uint32_t LONG3_FAST = 6;           // plain steps per turn: LONG3_FAST + 2 ops = half a piece, a piece arrives within a turn
 
+// (a struct out of the argument block: member by member, the copy constructor does not take the constant address space)
+template <class T>
+__device__ __forceinline__ T load_arg(const __attribute__((address_space(4))) T *src) {
+    T v;
+    __builtin_memcpy(&v, src, sizeof(T));
+    return v;
+}
+// k_scan_long3's argument block (see ShortArgs at k_scan_short for why): what only the staging of new alignments, the
+// packing of finished junctions and the pool's copy-out need is read from here at those points.
+struct Long3Args {
+    ScanParams p;
+    uint64_t n, n_words, base_read_index;
+    uint32_t reads_per_wave;
+    const int32_t *a_tid, *a_pos;
+    const uint16_t *a_flag;
+    const uint8_t *a_xs, *a_nh;
+    const uint32_t *a_off, *a_nc, *cigar, *tail, *rank_of_tid;
+    uint4 *items, *pays;
+    uint32_t *cnts;
+    uint8_t *digs;
+    uint64_t capacity;
+    Counters *counters;
+};
+static_assert(offsetof(Long3Args, reads_per_wave) == sizeof(ScanParams) + 24 && offsetof(Long3Args, a_tid) == sizeof(ScanParams) + 32 &&
+              offsetof(Long3Args, counters) == sizeof(ScanParams) + 152, "Long3Args must mirror k_scan_long3's parameter list");
+typedef const __attribute__((address_space(4))) Long3Args *Long3ArgsPtr;
+__device__ __forceinline__ Long3ArgsPtr fresh_long3_args() {
+    Long3ArgsPtr k = (Long3ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
                                                    uint32_t reads_per_wave,
                                                    const int32_t *__restrict__ a_tid,
@@ -685,19 +717,25 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
 
     auto flush = [&]() {
         __threadfence_block();
+        const Long3ArgsPtr ka = fresh_long3_args();
+        const ScanParams fp = load_arg(&ka->p);
+        uint4 *const ka_items = ka->items, *const ka_pays = ka->pays;
+        uint32_t *const ka_cnts = ka->cnts;
+        uint8_t *const ka_digs = ka->digs;
+        const uint64_t ka_capacity = ka->capacity;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(append_counter(counters, p, stripe), (unsigned long long)pool_n);
+        if (lane == 0) base = atomicAdd(append_counter(ka->counters, fp, stripe), (unsigned long long)pool_n);
         base = __shfl(base, 0);
         for (uint32_t k = lane; k < pool_n; k += 64) {
-            const uint64_t idx = append_index(p, stripe, base + k);
-            if (idx < capacity) {
+            const uint64_t idx = append_index(fp, stripe, base + k);
+            if (idx < ka_capacity) {
                 uint4 it = my_item[k];
                 it.w = (uint32_t)idx;
-                items[idx] = it;
+                ka_items[idx] = it;
                 const uint4 py = my_pay[k];
-                pays[idx] = py;
-                cnts[idx] = IPX_CNT_ONE(py.x & 3u);
-                digs[idx] = (uint8_t)ipx_digit_of(it, p.first);
+                ka_pays[idx] = py;
+                ka_cnts[idx] = IPX_CNT_ONE(py.x & 3u);
+                ka_digs[idx] = (uint8_t)ipx_digit_of(it, fp.first);
                 kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
                 kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
             }
@@ -744,14 +782,15 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
         if (pass) {
             const uint32_t slot = pool_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-            const unsigned long long ri = base_read_index + my_i;
+            const Long3ArgsPtr ka = fresh_long3_args();
+            const unsigned long long ri = ka->base_read_index + my_i;
             if (ordinal <= IPX_ORD_MAX_ORDINAL) {
                 ReadCtx c;
                 c.pos = 0; c.rank = rank; c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_index = ri;
                 uint4 it, pay;
                 const Rec r{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
                             (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
-                pack_record_rel(p, c, r, pos32, ordinal, it, pay);
+                pack_record_rel(load_arg(&ka->p), c, r, pos32, ordinal, it, pay);
                 my_item[slot] = it;
                 my_pay[slot] = pay;
             }
@@ -803,7 +842,7 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
             } else if (bad) {                                            // :312-313: the exception ends the read
                 const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
                 const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
-                const unsigned long long e = ((base_read_index + my_i) << IPX_ORD_SHIFT_READ) |
+                const unsigned long long e = ((fresh_long3_args()->base_read_index + my_i) << IPX_ORD_SHIFT_READ) |
                                              ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
                                              (IPX_ERRK_CIGAR << 8) | ch;
                 my_err = e < my_err ? e : my_err;
@@ -846,9 +885,11 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
                 ReadCtx c;
                 c.pos = (int32_t)pos32; c.flag = 0; c.nhc = 0; c.rank = rank;
                 c.strand = meta & 0xffu; c.cat = (meta >> 8) & 3u; c.read_rejected = (meta & 0x400u) != 0;
-                c.read_index = base_read_index + my_i;
-                (void)run_read<3>(p, c, cigar + a_off[my_i], a_nc[my_i], ordinal, capacity, items, pays, cnts, digs, kb,
-                                  my_err, append_counter(counters, p, stripe), stripe);
+                const Long3ArgsPtr ka = fresh_long3_args();
+                const ScanParams rp = load_arg(&ka->p);
+                c.read_index = ka->base_read_index + my_i;
+                (void)run_read<3>(rp, c, ka->cigar + ka->a_off[my_i], ka->a_nc[my_i], ordinal, ka->capacity, ka->items, ka->pays,
+                                  ka->cnts, ka->digs, kb, my_err, append_counter(ka->counters, rp, stripe), stripe);
                 redo = false;
             }
         }
@@ -865,11 +906,16 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
                     staged = rem < 64 ? (uint32_t)rem : 64u;
                     staged_used = 0;
                     if (lane < staged) {
+                        const Long3ArgsPtr ka = fresh_long3_args();
+                        const int32_t *const a_tid = ka->a_tid, *const a_pos = ka->a_pos;
+                        const uint16_t *const a_flag = ka->a_flag;
+                        const uint8_t *const a_xs = ka->a_xs, *const a_nh = ka->a_nh;
+                        const uint32_t *const a_off = ka->a_off, *const a_nc = ka->a_nc, *const rank_of_tid = ka->rank_of_tid;
                         const uint64_t i = next + lane;
                         const int32_t tid = a_tid[i];
                         uint32_t ncl = a_nc[i];
                         const uint32_t flag = a_flag[i];
-                        const unsigned long long ri = base_read_index + i;
+                        const unsigned long long ri = ka->base_read_index + i;
                         if (ncl <= 1 || tid < 0 || (flag & (F_QCFAIL | F_DUP))) ncl = 0;
                         if (ncl && (uint32_t)tid >= p.n_targets) {
                             const unsigned long long e = (ri << IPX_ORD_SHIFT_READ) | (IPX_ERRK_TARGET << 8);
@@ -1056,7 +1102,8 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
         const unsigned long long o = __shfl_xor(e, d);
         e = o < e ? o : e;
     }
-    if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters->err_word, e);
+    Counters *const counters_ = fresh_long3_args()->counters;
+    if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&counters_->err_word, e);
 
     uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
 #pragma unroll
@@ -1072,10 +1119,10 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
         const uint32_t x0 = kb_s[0][t], x1 = kb_s[1][t], x2 = kb_s[2][t], x3 = kb_s[3][t];
         if (t < 3) {
             const uint32_t o = x0 | x1 | x2 | x3;
-            if (o) atomicOr(&counters->key_or[t], o);
+            if (o) atomicOr(&counters_->key_or[t], o);
         } else {
             const uint32_t a = x0 & x1 & x2 & x3;
-            if (a != ~0u) atomicAnd(&counters->key_and[t - 3], a);
+            if (a != ~0u) atomicAnd(&counters_->key_and[t - 3], a);
         }
     }
 }
@@ -1224,13 +1271,6 @@ struct ShortArgs {
 static_assert(offsetof(ShortArgs, n) == sizeof(ScanParams) && offsetof(ShortArgs, a_tid) == sizeof(ScanParams) + 24 &&
               offsetof(ShortArgs, defer) == sizeof(ScanParams) + 152, "ShortArgs must mirror k_scan_short's parameter list");
 typedef const __attribute__((address_space(4))) ShortArgs *ShortArgsPtr;
-// (a struct out of the argument block: member by member, the copy constructor does not take the constant address space)
-template <class T>
-__device__ __forceinline__ T load_arg(const __attribute__((address_space(4))) T *src) {
-    T v;
-    __builtin_memcpy(&v, src, sizeof(T));
-    return v;
-}
 __device__ __forceinline__ ShortArgsPtr fresh_args() {
     ShortArgsPtr k = (ShortArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 // four bytes per step through slicing tables in LDS.  A block whose sum differs gets 0x100 OR-ed into its status.
 __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
                                                  const uint32_t *__restrict__ isize, const uint32_t *__restrict__ crc_expected,
-                                                 uint64_t n_blocks, uint32_t *__restrict__ status) {
+                                                 uint64_t n_blocks, uint32_t *__restrict__ status, uint32_t lanes_per_wave) {
     __shared__ uint32_t T[4][256];
     for (uint32_t i = threadIdx.x; i < 256; i += 64) {
         uint32_t c = i;
@@ -475,16 +475,28 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out
         for (uint32_t t = 1; t < 4; ++t) { c = T[0][c & 0xffu] ^ (c >> 8); T[t][i] = c; }
     }
     __syncthreads();
-    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x >= lanes_per_wave) return;              // (after the barriers above; as few lanes a wave as k_bgzf_inflate, for its reasons)
+    const uint64_t blk = (uint64_t)blockIdx.x * lanes_per_wave + threadIdx.x;
     if (blk >= n_blocks) return;
     const uint8_t *p = out + out_off[blk];
     const uint32_t n = isize[blk];
     uint32_t c = 0xffffffffu, i = 0;
-    for (; i < n && ((uintptr_t)(p + i) & 3u); ++i) c = T[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
-    for (; i + 4 <= n; i += 4) {
-        c ^= *reinterpret_cast<const uint32_t *>(p + i);
+    auto word = [&](uint32_t w) {
+        c ^= w;
         c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
+    };
+    for (; i < n && ((uintptr_t)(p + i) & 15u); ++i) c = T[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    // sixteen bytes a turn, the next sixteen asked for before this turn's look-ups (round 4: a 4-byte load per turn, waited
+    // for at once, made the sum a trip to memory per word -- 14 ms for 2.2 GB; the inflated stream ends in spare bytes)
+    if (i + 16 <= n) {
+        uint4 nxt = *reinterpret_cast<const uint4 *>(p + i);
+        for (; i + 16 <= n; i += 16) {
+            const uint4 cur = nxt;
+            nxt = *reinterpret_cast<const uint4 *>(p + i + 16);
+            word(cur.x); word(cur.y); word(cur.z); word(cur.w);
+        }
     }
+    for (; i + 4 <= n; i += 4) word(*reinterpret_cast<const uint32_t *>(p + i));
     for (; i < n; ++i) c = T[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
     if ((c ^ 0xffffffffu) != crc_expected[blk]) status[blk] |= 0x100u;
 }
@@ -553,9 +565,19 @@ static void launch_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *i
 hipError_t ipx_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *in_begin, const uint64_t *in_end,
                                    const uint32_t *isize, const uint64_t *out_off, const uint32_t *crc, uint64_t n_blocks,
                                    uint8_t *out, uint32_t *tables, uint32_t *status, const uint32_t *order) {
-    const dim3 grid((uint32_t)ipx_div_up(n_blocks, 64));
     launch_inflate(s, comp, in_begin, in_end, isize, out_off, n_blocks, out, tables, status, order);
-    if (crc) hipLaunchKernelGGL(k_bgzf_crc, grid, dim3(64), 0, s, out, out_off, isize, crc, n_blocks, status);
+    if (crc) {
+        // (lanes per wave as in launch_inflate: the sum's kernel fits eight waves on a SIMD, six are aimed at)
+        static const uint32_t crc_places = [] {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            return (uint32_t)cus * 24u;
+        }();
+        uint32_t lpw = (uint32_t)ipx_div_up(n_blocks, crc_places);
+        if (lpw < 1) lpw = 1;
+        if (lpw > 64) lpw = 64;
+        hipLaunchKernelGGL(k_bgzf_crc, dim3((uint32_t)ipx_div_up(n_blocks, lpw)), dim3(64), 0, s, out, out_off, isize, crc, n_blocks, status, lpw);
+    }
     return hipGetLastError();
 }
 

@@ -284,7 +284,7 @@ def test_cli_bam_inflated_on_the_device(cli, oracle_cli, golden, tmp_path):
                                stderr=subprocess.PIPE)
             digests.append(hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest())
             if env is env1:                      # it really took the device path: one push per target (or one in all), no reading time
-                tl = json.loads([l for l in r.stderr.decode().splitlines() if "ipx_timeline" in l][-1])["ipx_timeline"]
+                tl = json.loads([l for l in r.stderr.decode().splitlines() if l.startswith('{"ipx_timeline"')][-1])["ipx_timeline"]
                 assert tl["alignments"] == 300000 and tl["pushes"] <= 9 and tl["files_decoded_on_device"] == 1, tl
         assert digests[0] == digests[1] and os.path.getsize(tsv) > 10000
     # a file above IPX_DEVICE_INFLATE_MAX (megabytes) is not read whole: it goes through the ordinary reader's batches
@@ -293,7 +293,7 @@ def test_cli_bam_inflated_on_the_device(cli, oracle_cli, golden, tmp_path):
     assert os.path.getsize(aligned) > (2 << 20)
     r = subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed, aligned], check=True, stderr=subprocess.PIPE,
                        env=dict(env1, IPX_DEVICE_INFLATE_MAX="1"))
-    tl = json.loads([l for l in r.stderr.decode().splitlines() if "ipx_timeline" in l][-1])["ipx_timeline"]
+    tl = json.loads([l for l in r.stderr.decode().splitlines() if l.startswith('{"ipx_timeline"')][-1])["ipx_timeline"]
     assert tl["alignments"] == 300000 and tl["files_decoded_on_device"] == 0, tl
     sorted_digest = hashlib.sha256(open(tsv, "rb").read() + open(bed, "rb").read()).hexdigest()
     r0 = subprocess.run([cli, "--min-confidence-score=0.0", "-c", tsv, "-j", bed, aligned], check=True, env=env0, stderr=subprocess.PIPE)

@@ -86,6 +86,42 @@ def test_short_reads_in_random_order_match_oracle():
     assert np.array_equal(sorted_ora["counts"], ora["counts"]) and not np.array_equal(sorted_ora["ijunc"], ora["ijunc"])
 
 
+@pytest.mark.parametrize("n_reads", [511, 512, 513, 1023, 1025, 512 * 37 + 1, 512 * 40 - 1])
+def test_ragged_last_tile_of_the_short_read_scan(n_reads):
+    """k_scan_short works in tiles of 512 alignments whose fields are fetched from a CLAMPED index: a batch that ends one
+    alignment before, at, or after a tile boundary must count every read once and none twice (review of round 3, item 1)."""
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(n_reads, seed=700 + n_reads % 97, n_targets=2, target_len=2_800_000, n_sites=60)
+    dev, ora, err = _run_both(batch, names, {})
+    assert err is None
+    helpers.compare_tables(dev, ora)
+
+
+@pytest.mark.parametrize("k_out_of_place,flt", [(1, 0), (17, 0), (400, 0), (17, 2)])
+def test_sorted_input_with_a_few_reads_out_of_place(k_out_of_place, flt, tmp_path):
+    """Coordinate-sorted input in which k reads sit far from their place (what a merge of sorted files with a few
+    stragglers looks like): the tile combiner folds what is adjacent, the stragglers' records meet their junction's other
+    records only in the sort -- creators, counts and sjN must be the oracle's, also under the canonical-motif filter, where
+    a straggler may be the record that creates a junction (review of round 3, item 1)."""
+    from intronprospector_amd import synth
+    gen, fa = None, None
+    if flt:
+        batch, names, gen = synth.short_reads(90_000, seed=811, n_targets=3, target_len=2_800_000, n_sites=900, genome=True)
+        fa = str(tmp_path / "g.fa")
+        gen.write_fasta(fa)
+    else:
+        batch, names, _ = synth.short_reads(90_000, seed=810, n_targets=3, target_len=2_800_000, n_sites=900)
+    n = len(batch["tid"])
+    rng = np.random.default_rng(812 + k_out_of_place)
+    perm = np.arange(n)
+    src = rng.choice(n, size=k_out_of_place, replace=False)
+    dst = rng.choice(n, size=k_out_of_place, replace=False)
+    perm[src], perm[dst] = perm[dst].copy(), perm[src].copy()       # k pairs of reads trade places
+    dev, ora, err = _run_both(synth.permute_batch(batch, perm), names, {"junction_filter": flt}, genome=gen, fasta=fa, n_push=2)
+    assert err is None and "error" not in dev
+    helpers.compare_tables(dev, ora, _fetcher(gen) if gen is not None else None)
+
+
 def test_finalize_then_push_more_then_finalize_again():
     """The table may be asked for repeatedly while records accumulate (multi-input mode of the
     host): a second sort starts from an already permuted record array."""

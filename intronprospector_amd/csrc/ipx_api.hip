@@ -468,12 +468,24 @@ uint32_t ipx_abi_version(void) { return IPX_ABI_VERSION; }
 int ipx_create(const ipx_params *params, ipx_handle **out) {
     if (!params || !out) return IPX_EINVAL;
     *out = nullptr;
+    // IPX_DEBUG_PLAN: where the time of opening the device goes (it is a quarter of the command line's wall time)
+    const bool laps = getenv("IPX_DEBUG_PLAN") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!laps) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "ipx_create: %-32s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IPX_ENODEVICE;
+    lap("hipGetDeviceCount (runtime init)");
     if (params->device < 0 || params->device >= ndev) return IPX_ENODEVICE;
     if (hipSetDevice(params->device) != hipSuccess) return IPX_ENODEVICE;
+    lap("hipSetDevice");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, params->device) != hipSuccess) return IPX_ENODEVICE;
+    lap("hipGetDeviceProperties");
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return IPX_ENODEVICE;   // code objects are gfx950 only
     if (params->sj_filter < 0 || params->sj_filter > 2 || params->strandness < 0 || params->strandness > 2 ||
         params->scope < 0 || params->scope > 1)
@@ -495,6 +507,7 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
         }
     }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return IPX_EDEVICE; }
+    lap("stream");
     h->stream = h->own_stream;
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
@@ -507,13 +520,18 @@ int ipx_create(const ipx_params *params, ipx_handle **out) {
         if (hipHostGetDevicePointer(&d, m, 0) != hipSuccess) { ipx_destroy(h); return IPX_EDEVICE; }
         h->mail_dev = (uint32_t *)d;
     }
+    lap("events, pinned words");
     int rc = ensure(h, h->counters, IPX_COUNTERS_BYTES);      // layout: ipx_common.h
     if (!rc && hipMemsetAsync(h->counters.p, 0, IPX_COUNTERS_BYTES, h->stream) != hipSuccess) rc = IPX_EDEVICE;
     if (!rc) rc = ensure(h, h->close_ws, 2 * CLOSE_CAP * sizeof(unsigned long long));
     if (!rc) rc = ensure(h, h->d_small, 64 * sizeof(uint32_t));
+    lap("device words");
     if (!rc) rc = reset_counters(h);
+    if (laps) (void)hipStreamSynchronize(h->stream);
+    lap("first kernel (code objects)");
     if (!rc) rc = rebuild_ranks(h);
     if (rc) { ipx_destroy(h); return rc; }
+    lap("ranks");
     *out = h;
     return IPX_OK;
 }

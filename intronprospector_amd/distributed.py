@@ -462,9 +462,7 @@ class RecordExchanger:
         room = S - header_records
         rows = recv.view(world, S * 32)[:, 32:32 + 4 * world].contiguous().view(torch.int32).to(torch.int64).cpu()
         rows = rows & 0xffffffff                                      # (counts are unsigned 32-bit words)
-        tails = (rows - room).clamp_(min=0)                           # [sender][part]
-        send_counts = tails[rank].tolist()
-        recv_counts = tails[:, rank].tolist()
+        send_counts, recv_counts = tail_splits(rows, room, rank)
         n_send, n_recv = sum(send_counts), sum(recv_counts)
         if n_send * 32 > self._spill.numel():
             raise RuntimeError("record exchange: the spill is smaller than the tails (%d records)" % n_send)
@@ -569,6 +567,14 @@ class RecordExchanger:
         t0 = self._lap("global_ijunc", t0)
         self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
         return table, ijunc
+
+
+def tail_splits(counts, room, rank):
+    """counts[s][p]: records sender s has for part p (what the slot headers carry); room: records a slot holds.
+    -> (what `rank` sends to every peer, what it receives from every peer) in the second all_to_all of an exchange whose
+    slots overflowed: the part of every count beyond `room`."""
+    tails = (counts.to(torch.int64) - int(room)).clamp_(min=0)
+    return [int(x) for x in tails[rank].tolist()], [int(x) for x in tails[:, rank].tolist()]
 
 
 class SlotOverflow(Exception):

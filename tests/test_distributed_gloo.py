@@ -254,3 +254,20 @@ def test_config5_shares_and_cross_rank_checks(oracle_lib):
     # rank 0: chunks 0..11 whole and the first half of 12; rank 1: the second half of 12, then 13..24
     assert p0[0] == (0, 0, 4000) and p0[-1] == (12, 0, 2000) and len(p0) == 13
     assert p1[0] == (12, 2000, 4000) and p1[-1] == (24, 0, 4000) and len(p1) == 13
+
+
+def test_tail_splits_of_an_overflowed_slotted_exchange():
+    """RecordExchanger._exchange_tails derives the split sizes of its second all_to_all from the counts matrix that the
+    slot headers carry: every rank must send exactly what its peer expects, and nothing where the slot had room."""
+    import torch
+    from intronprospector_amd.distributed import tail_splits
+    counts = torch.tensor([[10, 0, 700], [512, 513, 5], [0, 2000, 511]], dtype=torch.int64)      # [sender][part]
+    room = 512
+    sends, recvs = zip(*(tail_splits(counts, room, r) for r in range(3)))
+    assert sends == ([0, 0, 188], [0, 1, 0], [0, 1488, 0])
+    for s in range(3):
+        for p in range(3):
+            assert sends[s][p] == recvs[p][s]                   # what s sends to p is what p expects from s
+    assert sum(map(sum, sends)) == 188 + 1 + 1488
+    assert tail_splits(torch.zeros((2, 2), dtype=torch.int64), 64, 1) == ([0, 0], [0, 0])
+

@@ -608,13 +608,15 @@ extern "C" int ipx_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t n_
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = IPX_OK;
     auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == IPX_OK) rc = IPX_EDEVICE; return e == hipSuccess; };
-    ok(hipMalloc(&d_comp, n_bytes + 8)) && ok(hipMalloc(&d_out, out_bytes + 8)) && ok(hipMalloc(&d_in_off, 8 * (n_blocks + 1))) &&
+    // (spare bytes behind both buffers, as ipx_decode_bgzf has them: the bit reader asks for the word behind the one in use,
+    // a short match loads four whole words of its source)
+    ok(hipMalloc(&d_comp, n_bytes + 16)) && ok(hipMalloc(&d_out, out_bytes + 64)) && ok(hipMalloc(&d_in_off, 8 * (n_blocks + 1))) &&
         ok(hipMalloc(&d_out_off, 8 * n_blocks)) && ok(hipMalloc(&d_isize, 4 * n_blocks)) &&
         ok(hipMalloc(&d_tables, 4ull * LANE_WORDS * n_blocks)) && ok(hipMalloc(&d_status, 4 * n_blocks)) &&
         ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1));
     if (rc == IPX_OK) {
         ok(hipMemcpy(d_comp, comp, n_bytes, hipMemcpyHostToDevice));
-        ok(hipMemset(d_comp + n_bytes, 0, 8));
+        ok(hipMemset(d_comp + n_bytes, 0, 16));
         ok(hipMemcpy(d_in_off, in_off, 8 * (n_blocks + 1), hipMemcpyHostToDevice));
         ok(hipMemcpy(d_out_off, out_off, 8 * n_blocks, hipMemcpyHostToDevice));
         ok(hipMemcpy(d_isize, isize, 4 * n_blocks, hipMemcpyHostToDevice));

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include <algorithm>
+#include <map>
 #include <cctype>
 #include <stdexcept>
 
@@ -720,9 +721,12 @@ void JunctionsExtractor::finalize_table() {
     t_finalize_ += t1 - t0;
     struct RowTimer { double &acc; double t0; bool on; ~RowTimer() { if (on) acc += now_s() - t0; } } row_timer{t_table_, t1, timeline_};
     if (rc != IPX_OK) throw_last_error(rc);
+    // Rows are independent of each other (a row's confidence is an entropy over ITS read offsets: 2 M logarithms for
+    // 200 000 junctions): large tables are filled by a few threads, each its own range of rows.
     table_.clear();
-    table_.reserve(t.n_junctions);
-    for (uint64_t i = 0; i < t.n_junctions; ++i) {
+    table_.resize(t.n_junctions);
+    auto fill_rows = [&](uint64_t row_lo, uint64_t row_hi) {
+    for (uint64_t i = row_lo; i < row_hi; ++i) {
         Junction j;
         j.chrom = targets_[t.target[i]];
         j.intron_start = t.intron_start[i];
@@ -762,7 +766,22 @@ void JunctionsExtractor::finalize_table() {
         }
         const uint64_t hb = t.hist_begin[i], he = t.hist_begin[i + 1];
         j.confidence = confidence_from_histogram(t.hist_count + hb, he - hb, j.total_read_count());
-        table_.push_back(std::move(j));
+        table_[i] = std::move(j);
+    }
+    };
+    {
+        const unsigned want = t.n_junctions >= 20000 ? std::min(8u, std::max(1u, BgzfReader::usable_cpus() / 2)) : 1u;
+        if (want <= 1) {
+            fill_rows(0, t.n_junctions);
+        } else {
+            std::vector<std::thread> workers;
+            const uint64_t step = (t.n_junctions + want - 1) / want;
+            for (unsigned k = 0; k < want; ++k) {
+                const uint64_t lo = std::min<uint64_t>(t.n_junctions, (uint64_t)k * step), hi = std::min<uint64_t>(t.n_junctions, lo + step);
+                if (lo < hi) workers.emplace_back(fill_rows, lo, hi);
+            }
+            for (std::thread &w : workers) w.join();
+        }
     }
     // missing-sequence warnings, once per chromosome, in the order the reference meets them
     // (junctions_extractor.cc:411-416): first record on a chromosome the genome does not hold
@@ -789,8 +808,22 @@ void JunctionsExtractor::finalize_table() {
         if (trace_fh_) write_trace(t, recs);
         if (!pt_pending_.empty()) write_pending_pass_through(t, recs);
     }
-    std::stable_sort(table_.begin(), table_.end(),
-                     [](const Junction &a, const Junction &b) { return a.chrom < b.chrom; });
+    // (through the names' ranks: the same order as comparing the strings, see junctions.cc)
+    {
+        std::map<std::string, uint32_t> rank_of;
+        for (const std::string &name : targets_) rank_of.emplace(name, 0u);
+        uint32_t next = 0;
+        for (auto &kv : rank_of) kv.second = next++;
+        std::vector<uint32_t> rank_of_target(targets_.size());
+        for (size_t k = 0; k < targets_.size(); ++k) rank_of_target[k] = rank_of[targets_[k]];
+        std::vector<uint32_t> idx(table_.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return rank_of_target[t.target[a]] < rank_of_target[t.target[b]]; });
+        JunctionVector sorted;
+        sorted.reserve(table_.size());
+        for (uint32_t i : idx) sorted.push_back(std::move(table_[i]));
+        table_.swap(sorted);
+    }
     table_valid_ = true;
 }
 

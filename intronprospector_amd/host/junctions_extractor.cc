@@ -440,7 +440,13 @@ void JunctionsExtractor::FileLoad::drop() {
     failed = true;
     for (std::thread &t : readers) t.join();
     readers.clear();
-    free(buf);
+    // (giving a gigabyte back to the system takes tens of milliseconds: nobody has to wait for it)
+    if (buf && size >= ((size_t)64 << 20)) {
+        uint8_t *p = buf;
+        std::thread([p] { free(p); }).detach();
+    } else {
+        free(buf);
+    }
     buf = nullptr;
     size = 0;
 }

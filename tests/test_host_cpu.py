@@ -37,6 +37,17 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.ipx_abi_version() == 4
 
 
+def test_the_per_operation_scan_is_a_library_of_its_own():
+    """round 4: k_scan_ops is test-only and lives in libipx_scanops.so, which libipx.so loads on IPX_SCAN=ops; the product
+    library holds nothing of it"""
+    from intronprospector_amd import _lib
+    ops = os.path.join(os.path.dirname(_lib.LIB_PATH), "libipx_scanops.so")
+    assert os.path.exists(ops), "make -C intronprospector_amd/csrc builds it"
+    assert hasattr(ctypes.CDLL(ops), "ipx_scanops_launch")
+    names = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, stdout=subprocess.PIPE).stdout.decode()
+    assert "scan_ops" not in names and "scanops" not in names
+
+
 def test_product_fails_loudly_without_a_device():
     """No CPU fallback: without a GPU the product path raises instead of computing."""
     import torch

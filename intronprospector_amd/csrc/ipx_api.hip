@@ -754,7 +754,7 @@ static int push_launch(ipx_handle *h) {
     pp.use_stripes = true;
     pp.attempt = 0;
     // list of the alignments k_scan_short hands on to k_scan_rest (at most all of them)
-    if ((rc = ensure(h, h->defer, (size_t)n * sizeof(uint32_t) + 256))) return rc;
+    if ((rc = ensure(h, h->defer, ipx_scan_list_words(n) * sizeof(uint32_t)))) return rc;
     ProfScope prof_scope(&h->prof);
     if ((rc = launch_scan_attempt(h))) return rc;
     pp.active = true;

@@ -311,10 +311,8 @@ void ipx_prof_mark(hipStream_t s, int id);
 // before a launch of class id: opens the interval when that class alone is being timed (ipx_profile_only)
 void ipx_prof_pre(hipStream_t s, int id);
 
-// words of the `defer` workspace ipx_launch_scan needs for a batch of n alignments: k_scan_rest's list (n), then
-// k_scan_short3's per-wave counts and per-wave lists for k_scan_walk (every wave as many slots as it scans alignments)
-constexpr uint32_t IPX_SCAN_MAX_WAVES = 16384;
-static inline size_t ipx_scan_list_words(uint64_t n) { return (size_t)(2 * n + 64 + IPX_SCAN_MAX_WAVES + (size_t)IPX_SCAN_MAX_WAVES * 128 + 64); }
+// words of the `defer` workspace ipx_launch_scan needs for a batch of n alignments (k_scan_rest's list)
+static inline size_t ipx_scan_list_words(uint64_t n) { return (size_t)n + 64; }
 
 // ---- launchers implemented in the kernel translation units -------------------
 // ipx_scan.hip

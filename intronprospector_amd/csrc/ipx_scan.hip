@@ -2222,11 +2222,10 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     p.n_stripes = (blocks >= 64 && close_ws && close_cap) ? IPX_STRIPES : 0;
     static const bool short_old = [] { const char *e = getenv("IPX_SHORT_OLD"); return e && e[0] == '1'; }();
     if (short_reads && !short_old) {
-        // k_scan_short3 + k_scan_walk (ipx_scan_short.inc): a wave per 128 alignments, six blocks of four waves per CU
+        // k_scan_short3 (ipx_scan_short.inc): a wave per 128 alignments, six blocks of four waves per CU
         uint64_t blocks3 = ipx_div_up(b.n_alignments, (uint64_t)S3_WT * S3_NW);
         const uint64_t resident3 = (uint64_t)n_cus * 6u;
         if (blocks3 > resident3) blocks3 = resident3;
-        const uint64_t waves3 = blocks3 * S3_NW, n_wtiles = ipx_div_up(b.n_alignments, S3_WT);
         p.n_stripes = (blocks3 >= 64 && close_ws && close_cap) ? IPX_STRIPES : 0;
         Short3Args a{};
         a.p = p;
@@ -2235,17 +2234,11 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         a.cigar = b.cigar; a.cigar8 = b.n_cigar_words >= 8 ? b.cigar : tail; a.tail = tail; a.rank_of_tid = rank_of_tid;
         a.items = items; a.pays = pays; a.cnts = cnts; a.digs = digs; a.capacity = capacity; a.counters = counters;
         a.defer = defer;
-        // the walk lists live behind k_scan_rest's list (ipx_scan_list_words): per wave as many slots as it scans alignments
-        a.walk_cap = (uint32_t)(ipx_div_up(n_wtiles, waves3) * S3_WT);
-        a.walk_n = defer + b.n_alignments + 64;
-        a.walk_list = a.walk_n + IPX_SCAN_MAX_WAVES;
         a.comb_on = p.combine;
         if (p.combine == 2u) {
             hipLaunchKernelGGL((k_scan_short3<1>), dim3((uint32_t)blocks3), dim3(64 * S3_NW), 0, s, a);
-            hipLaunchKernelGGL((k_scan_walk<1>), dim3((uint32_t)blocks3), dim3(64 * S3_NW), 0, s, a);
         } else {
             hipLaunchKernelGGL((k_scan_short3<0>), dim3((uint32_t)blocks3), dim3(64 * S3_NW), 0, s, a);
-            hipLaunchKernelGGL((k_scan_walk<0>), dim3((uint32_t)blocks3), dim3(64 * S3_NW), 0, s, a);
         }
     } else if (short_reads)
         hipLaunchKernelGGL((k_scan_short<2, 768, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,

@@ -754,9 +754,9 @@ def _pileup(cigars, n, seed, n_pos=40, nh_mix=True):
     ["50M500N50M", "30M100N20M200N50M", "2S28M100N20M200N50M", "30M100N10M1D9M200N50M"],
 ])
 def test_pile_up_tiles_fold_before_they_overflow_the_pool(cigars, monkeypatch):
-    """k_scan_short's early combine: a tile whose records would not fit the LDS pool folds what it has and goes
-    on (round 1 sent such tiles to the slow second stage, uncombined); against the oracle, and against the
-    combiner switched off"""
+    """pile-ups: thousands of copies of a handful of (junction, offset) pairs, the copies of different pairs
+    alternating in the input -- the scan folds them (runs in registers, the rest in its pool) instead of handing
+    every copy to the sort; against the oracle, and against the combiner switched off"""
     monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")        # the short-CIGAR kernel whatever the mean CIGAR length
     batch = _pileup(cigars, 40_000, seed=len(cigars))
     p = {"min_anchor_length": 8, "max_anchor_indel_size": 3}
@@ -768,8 +768,10 @@ def test_pile_up_tiles_fold_before_they_overflow_the_pool(cigars, monkeypatch):
     folded = ex.records_pending()
     ex.close()
     # a few hundred keys, tens of thousands of records; reads of more than 8 ops (a third of the second case)
-    # go through the second stage, which does not fold
-    limit = dev["n_records"] * (0.6 if any(len(_cig(c)) > 8 for c in cigars) else 0.05)
+    # go through the second stage, which does not fold.  (Round 5: a WAVE owns a tile of 128 alignments and a batch of
+    # this size gives every wave one tile, so what is left is a handful of records per 128 alignments -- keys that
+    # alternate in the input, the third case, are folded by the pool's second fold, k_scan_short3's dedupe)
+    limit = dev["n_records"] * (0.6 if any(len(_cig(c)) > 8 for c in cigars) else 0.08)
     assert folded < limit, (folded, dev["n_records"])
     monkeypatch.setenv("IPX_COMBINE", "0")
     dev0, _, _ = _run_both(batch, ["chr1"], p)

@@ -90,10 +90,10 @@ struct ScanParams {
     uint32_t n_targets;
     KeyLayout key;
     DigitSpec first;      // window of the digit bytes written next to the records (the first sort pass)
-    // Where a launch's records go.  n_stripes == 0: appended at Counters::n_records.  n_stripes == 8: the
+    // Where a launch's records go.  n_stripes == 0: appended at Counters::n_records.  n_stripes == IPX_STRIPES: the
     // launch fills IPX_STRIPES interleaved stripes after the `base` records the handle already holds, one
-    // counter per stripe (a block uses the stripe of the XCD it runs on): one returning atomic per tile
-    // on a single word saturates at ~60-90 M/s, eight words on eight lines do not.  ipx_launch_scan then
+    // counter per stripe (a wave uses a stripe of the XCD it runs on): one returning atomic per reservation
+    // on a single word saturates at ~60-90 M/s, thirty-two words on thirty-two lines do not.  ipx_launch_scan then
     // closes the gaps the stripes leave, so everybody else sees base + n dense records.
     uint64_t base;
     uint32_t n_stripes;
@@ -114,13 +114,18 @@ struct ScanParams {
     uint32_t rank_is_tid;
     GenomeDev genome;
 };
-constexpr uint32_t IPX_STRIPES = 8;
-constexpr uint32_t IPX_STRIPE_CHUNK_BITS = 11;       // 2048 records: stripe s owns chunks s, s + 8, s + 16, ...
-// The Counters allocation (2 KiB): Counters at 0, the copy of the CIGAR array's tail at 128 (ipx_scan.hip),
-// stripe counters at 256 + 128 * s, gap-closing counters at 1280 / 1408, length of the list of alignments
-// k_scan_short leaves to k_scan_rest at 1536, number of records the tile combiner merged into others at 1544.
-constexpr uint32_t IPX_COUNTERS_BYTES = 2048, IPX_CNT_TAIL = 128, IPX_CNT_STRIPE0 = 256, IPX_CNT_CLOSE = 1280,
-                   IPX_CNT_DEFER = 1536, IPX_CNT_MERGED = 1544;
+constexpr uint32_t IPX_STRIPES = 32;                 // four per XCD
+constexpr uint32_t IPX_STRIPE_CHUNK_BITS = 9;        // 512 records: stripe s owns chunks s, s + 32, s + 64, ...
+// the stripe of a wave: the XCD it runs on (HW_REG_XCC_ID) and a number the kernel picks (its wave in the block)
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t ipx_stripe_of(uint32_t xcc_id, uint32_t sub) { return ((xcc_id & 7u) << 2) | (sub & 3u); }
+#endif
+// The Counters allocation (8 KiB): Counters at 0, the copy of the CIGAR array's tail at 128 (ipx_scan.hip), length of the
+// list of alignments the short-read scan leaves to k_scan_rest at 1536, number of records the scan's folds merged into
+// others at 1544 (the words behind it: ipx_api.hip), k_close's count of finished blocks at 1664, stripe counters at
+// 2048 + 128 * s.
+constexpr uint32_t IPX_COUNTERS_BYTES = 8192, IPX_CNT_TAIL = 128, IPX_CNT_DEFER = 1536, IPX_CNT_MERGED = 1544,
+                   IPX_CNT_CLOSE_DONE = 1664, IPX_CNT_STRIPE0 = 2048;
 
 // device-side counters of one handle (one cache line apart is not needed: they
 // are touched once per wave at most)

@@ -71,10 +71,11 @@ __device__ __forceinline__ bool qc_pass(const ScanParams &p, const ReadCtx &c, c
 struct KeyBits { uint32_t o0, o1, o2, a0, a1, a2; };
 
 // ---- where records go (ScanParams::base / n_stripes, ipx_common.h) -------------------------------
-__device__ __forceinline__ uint32_t my_stripe(const ScanParams &p) {
-    // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on.  Any value is correct; the XCD's own
-    // keeps a stripe's counter line in one place.
-    return p.n_stripes ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & (IPX_STRIPES - 1)) : 0u;
+__device__ __forceinline__ uint32_t my_stripe(const ScanParams &p, uint32_t sub = 0) {
+    // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this wave runs on.  Any value is correct; the XCD's own keeps a stripe's
+    // counter line in one place.  Four stripes per XCD (`sub`: the wave's number in its block): thirty-two counters, so
+    // that a launch whose waves reserve often -- input in random order, where nothing folds -- does not queue on eight.
+    return p.n_stripes ? ipx_stripe_of((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20), sub) : 0u;
 }
 __device__ __forceinline__ unsigned long long *append_counter(Counters *c, const ScanParams &p, uint32_t stripe) {
     return p.n_stripes ? reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c) + IPX_CNT_STRIPE0 + 128 * stripe)
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, 4) void k_scan_long(ScanParams p, uint64_t n, 
     if (next > n) next = n;
     uint32_t staged = 0, staged_used = 0;         // alignments in the stage / already handed out
     uint32_t pool_n = 0;
-    const uint32_t stripe = my_stripe(p);
+    const uint32_t stripe = my_stripe(p, threadIdx.x >> 6);
 
     auto flush = [&]() {
         __threadfence_block();
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
     if (next > n) next = n;
     uint32_t staged = 0, staged_used = 0;         // alignments in the stage / already handed out
     uint32_t pool_n = 0;
-    const uint32_t stripe = my_stripe(p);
+    const uint32_t stripe = my_stripe(p, threadIdx.x >> 6);
 
     auto flush = [&]() {
         __threadfence_block();
@@ -1127,19 +1128,9 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n,
     }
 }
 
-// ---- short CIGARs, second generation ------------------------------------------------------------
-// k_scan_short: k_scan's tile structure (one lane per alignment, RPT alignments per thread, records
-// staged in an LDS pool, ONE global atomic per tile) around closed forms for the plain spliced reads and the
-// select-based walk of k_scan_long for the rest.  A CIGAR of up to 8 ops arrives as two 16-byte loads instead
-// of one dependent 4-byte load per op; the eight ops run unrolled (the wave leaves when all its lanes are
-// done); 8 ops of < 2^28 cannot carry out of 32-bit offsets.  A finished junction is snapshotted; snapshots
-// are QC'd, packed and stored for all lanes of the wave at once -- when a lane is about to finish a second
-// junction, and at the end.  The alignments that need the walk wait in an LDS list across tiles until a
-// block's worth of them has come together (round 3: with one wave walking a tile's few while the others
-// waited at the barrier the walk was a third of a tile's time; 322 -> 281 us on S).
-// Alignments with more than 8 ops in such a batch (a few per cent at most), and whole tiles whose records
-// overflow the pool, are only LISTED (defer[], counted at IPX_CNT_DEFER) and left to k_scan_rest: with the
-// op-by-op walk inlined here the kernel needed 117 VGPRs (4 waves per SIMD), without it 87 (5 waves).
+// ---- short CIGARs: what k_scan_short3 (ipx_scan_short.inc) and k_scan_rest share ---------------------------------
+// (rounds 1-4's k_scan_short -- a 512-alignment tile per block, an LDS pool behind block barriers, the hash-table
+// combiner -- is in the history at 0be155e; ipx_scan_short.inc says what replaced it and why)
 struct AlnArrays {
     const int32_t *__restrict__ tid;
     const int32_t *__restrict__ pos;
@@ -1230,783 +1221,6 @@ __device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
     return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(c) + IPX_CNT_DEFER);
 }
 
-// -DIPX_SCAN_STATS: where a block's cycles go, tile phase by tile phase (s_memtime on thread 0; a few blocks print)
-#ifdef IPX_SCAN_STATS
-#define IPX_ST_DECL unsigned long long st_t0 = 0, st_ph[6] = {0, 0, 0, 0, 0, 0}; uint32_t st_tiles = 0
-#define IPX_ST_START st_t0 = __builtin_readcyclecounter()
-#define IPX_ST_LAP(k) do { const unsigned long long st_now = __builtin_readcyclecounter(); st_ph[k] += st_now - st_t0; st_t0 = st_now; } while (0)
-#else
-#define IPX_ST_DECL
-#define IPX_ST_START
-#define IPX_ST_LAP(k)
-#endif
-
-// BARRIERS (audited in round 4, after the divergent barrier of rounds 2-3: see "Everybody has read the count" below).
-// Every __syncthreads() of this kernel that sits under a condition carries a note "(uniform: ...)" naming why all threads
-// of the block evaluate that condition alike.  The rule they all follow: a condition that guards a barrier is computed
-// only from (a) kernel arguments and blockIdx, (b) loop counters that every thread steps alike, (c) a shared-memory word
-// that was last written BEFORE a barrier which every thread has passed, and is not written again until every thread has
-// passed a LATER barrier -- i.e. there is a barrier between the last write and the read, and one between the read and
-// the next write.  (c) is the one that was violated: pool_n was read for the early-combine test while faster threads
-// already added the next round's records to it.
-// k_scan_short's argument block as the ABI lays it out (kernarg segment; every member naturally aligned).  The kernel
-// holds more uniform values than a wave has scalar registers (121 were spilled to lanes of vector registers and read back
-// with v_readlane, the most frequent instruction of the kernel): what a tile needs only once, at its copy-out, is read from
-// here at that point instead of being kept (fresh_args: the empty asm makes the pointer opaque, so the loads stay where
-// they are written).
-struct ShortArgs {
-    ScanParams p;
-    uint64_t n, n_words, base_read_index;
-    const int32_t *a_tid, *a_pos;
-    const uint16_t *a_flag;
-    const uint8_t *a_xs, *a_nh;
-    const uint32_t *a_off, *a_nc, *cigar, *tail, *rank_of_tid;
-    uint4 *items, *pays;
-    uint32_t *cnts;
-    uint8_t *digs;
-    uint64_t capacity;
-    Counters *counters;
-    uint32_t *defer;
-};
-static_assert(offsetof(ShortArgs, n) == sizeof(ScanParams) && offsetof(ShortArgs, a_tid) == sizeof(ScanParams) + 24 &&
-              offsetof(ShortArgs, defer) == sizeof(ScanParams) + 152, "ShortArgs must mirror k_scan_short's parameter list");
-typedef const __attribute__((address_space(4))) ShortArgs *ShortArgsPtr;
-__device__ __forceinline__ ShortArgsPtr fresh_args() {
-    ShortArgsPtr k = (ShortArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    return k;
-}
-
-template <uint32_t RPT, uint32_t POOL, uint32_t BT>
-__global__ __launch_bounds__(BT, 5) void k_scan_short(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
-                                                    const int32_t *__restrict__ a_tid,
-                                                    const int32_t *__restrict__ a_pos,
-                                                    const uint16_t *__restrict__ a_flag,
-                                                    const uint8_t *__restrict__ a_xs,
-                                                    const uint8_t *__restrict__ a_nh,
-                                                    const uint32_t *__restrict__ a_off,
-                                                    const uint32_t *__restrict__ a_nc,
-                                                    const uint32_t *__restrict__ cigar,
-                                                    const uint32_t *__restrict__ tail,
-                                                    const uint32_t *__restrict__ rank_of_tid,
-                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                    uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
-                                                    uint64_t capacity, Counters *counters,
-                                                    uint32_t *__restrict__ defer) {
-    constexpr uint32_t NW = BT / 64;                 // waves per block
-    __shared__ uint32_t kb_s[NW][6];
-    KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
-    __shared__ unsigned long long tile_slot;
-    __shared__ uint4 pool_item[POOL], pool_pay[POOL];
-    __shared__ uint32_t pool_n;
-    // alignments that need the walk (batch indices): they wait here, across tiles, until a whole block's worth of
-    // them has come together -- see "the walks" below
-    __shared__ uint32_t dx_list[BT * RPT + BT];
-    __shared__ uint32_t dx_n;
-    // the tile combiner (ScanParams::combine): open-addressing table of pool indices, one per distinct key
-    constexpr uint32_t HT_BITS = POOL > 384 ? 10 : (POOL > 192 ? 9 : 8), HT = 1u << HT_BITS;   // >= 4/3 POOL
-    constexpr uint32_t CR = (POOL + BT - 1) / BT;                                              // pool rounds per thread
-    constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DEAD = 0xffffffffu;
-    static_assert(HT * 3 >= POOL * 4 && POOL <= IPX_CNT_MASK, "combiner table / count word too small for the pool");
-    __shared__ uint32_t ht[HT];
-    __shared__ uint32_t live_n[CR][NW];
-    static_assert(POOL >= 3 * BT, "a walk pass (BT alignments of at most eight ops, three records each) must fit the pool");
-    unsigned long long merged_acc = 0;            // thread 0: records merged into others by this block
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint64_t n_tiles = (n + (uint64_t)BT * RPT - 1) / ((uint64_t)BT * RPT);
-    const uint32_t stripe = my_stripe(p);
-    // slots of the tile's pool for the lanes of `mask` (one LDS atomic per wave)
-    auto pool_slot = [&](unsigned long long mask) {
-        const int first = __ffsll(mask) - 1;
-        uint32_t base = 0;
-        if ((int)lane == first) base = atomicAdd(&pool_n, (uint32_t)__popcll(mask));
-        return __shfl(base, first) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    };
-
-    // (the batch's arrays: read from the argument block where a tile or a walk pass begins, see ShortArgs)
-    auto fresh_aln = [&]() {
-        const ShortArgsPtr ka = fresh_args();
-        return AlnArrays{ka->a_tid, ka->a_pos, ka->a_flag, ka->a_xs, ka->a_nh, ka->a_off, ka->a_nc, ka->rank_of_tid,
-                         ka->n, ka->n_words, ka->base_read_index};
-    };
-
-    IPX_ST_DECL;
-    unsigned long long my_err = IPX_ERRW_NONE;
-    if (t == 0) dx_n = 0;
-    __syncthreads();
-    // (barriers inside: `total`, `final_pass`, `recombine` are the caller's block-uniform values -- see the call sites --,
-    // and the branches that hold barriers test nothing else: `if (recombine)`, `if (!final_pass)`; the per-round
-    // `if (r * BT >= total) continue` skips no barrier)
-    auto combine_pool = [&](const uint32_t total, const bool final_pass, const bool recombine) {
-        const ScanParams cp = load_arg(&fresh_args()->p);             // (what the combiner needs of the parameters, read here: see ShortArgs)
-        for (uint32_t k = t; k < HT; k += BT) ht[k] = HT_EMPTY;
-        __syncthreads();
-        // ---- combine: records of the tile with the same 96-bit key (junction AND read offset) become one.
-        // Coordinate-sorted input piles the reads of a hot junction up next to each other, so most of a
-        // tile's records are copies of a few keys: everything downstream (sort, heads, reduce, a multi-GPU
-        // exchange) then handles one record per key and tile.  What a group keeps is what the reduce would
-        // have made of its members anyway: the smallest order64 (with that record's strand), the smallest
-        // anchor start, the largest anchor end, the reads per category (item.w, IPX_CNT_*; it is 0 in the
-        // pool).  The first record of a key to claim a table slot OWNS the group, the others add themselves
-        // to the owner's pool entry with LDS atomics and die.  A wave whose lanes mostly hold ONE key (the
-        // pile-up case) first folds those lanes with shuffles, so the atomics run once per wave, not 64
-        // times on one address.  Records whose category lookup would throw (cat 3) stay as they are.
-        // active junction filter: only records that pass it may stand for others (ScanParams::combine); the
-        // others stay what they are, one read each.  The genome look-ups of all rounds go out together.
-        // fold the wave's copies of its first live key with shuffles, then claim / find the key's owner in the
-        // table and add this record (or the wave's fold) to the owner's pool entry
-        auto fold_and_insert = [&](uint32_t k, const uint4 &it, uint32_t cat, unsigned long long ord, uint32_t lo,
-                                   uint32_t hi, uint32_t cw, bool live) {
-            bool dead = false;
-            const unsigned long long lm = ipx_ballot(live);
-            if (lm) {
-                const int f = __ffsll(lm) - 1;
-                const uint32_t fx = __builtin_amdgcn_readlane(it.x, f), fy = __builtin_amdgcn_readlane(it.y, f),
-                               fz = __builtin_amdgcn_readlane(it.z, f);
-                const bool same = live && it.x == fx && it.y == fy && it.z == fz;
-                const unsigned long long sm = ipx_ballot(same);
-                if (__popcll(sm) >= 8) {
-                    // In a pile-up the first lane usually holds the extremes already (pool slots follow the
-                    // reads' order, copies of one key share the position and mostly the anchors): a compare and
-                    // a ballot per field tell, and the six-level butterflies (84 instructions for the three
-                    // fields) run only for a field some lane improves.
-                    const unsigned long long ord_f = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(ord >> 32), f) << 32) |
-                                                     __builtin_amdgcn_readlane((uint32_t)ord, f);
-                    const uint32_t lo_f = __builtin_amdgcn_readlane(lo, f), hi_f = __builtin_amdgcn_readlane(hi, f);
-                    unsigned long long o = ord_f;
-                    uint32_t l = lo_f, h = hi_f;
-                    if (ipx_ballot(same && ord < ord_f)) {
-                        o = same ? ord : ~0ull;
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) {
-                            const unsigned long long o2 = __shfl_xor(o, d);
-                            o = o2 < o ? o2 : o;
-                        }
-                    }
-                    if (ipx_ballot(same && lo < lo_f)) {
-                        l = same ? lo : ~0u;
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) {
-                            const uint32_t l2 = __shfl_xor(l, d);
-                            l = l2 < l ? l2 : l;
-                        }
-                    }
-                    if (ipx_ballot(same && hi > hi_f)) {
-                        h = same ? hi : 0u;
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) {
-                            const uint32_t h2 = __shfl_xor(h, d);
-                            h = h2 > h ? h2 : h;
-                        }
-                    }
-                    uint32_t c0, c1, c2;
-                    if (!recombine) {                                           // one read per lane: count lanes
-                        c0 = (uint32_t)__popcll(ipx_ballot(same && cat == 0u));
-                        c1 = (uint32_t)__popcll(ipx_ballot(same && cat == 1u));
-                        c2 = (uint32_t)__popcll(ipx_ballot(same && cat == 2u));
-                    } else {                                                    // lanes may stand for several reads
-                        uint32_t w01 = same ? ((cw & IPX_CNT_MASK) | (((cw >> IPX_CNT_BITS) & IPX_CNT_MASK) << 16)) : 0u;
-                        uint32_t w2 = same ? (cw >> (2 * IPX_CNT_BITS)) : 0u;
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) { w01 += __shfl_xor(w01, d); w2 += __shfl_xor(w2, d); }
-                        c0 = w01 & 0xffffu; c1 = w01 >> 16; c2 = w2;
-                    }
-                    if ((int)lane == f) {
-                        ord = o; lo = l; hi = h;
-                        cw = c0 | (c1 << IPX_CNT_BITS) | (c2 << (2 * IPX_CNT_BITS));
-                    } else if (same) {
-                        live = false;
-                        dead = true;
-                    }
-                }
-            }
-            if (live) {
-                uint32_t hs = it.x * 0x9E3779B1u;
-                hs ^= it.y * 0x85EBCA77u;
-                hs ^= it.z * 0xC2B2AE3Du;
-                hs ^= hs >> 15;
-                hs = (hs * 0x2C1B3C6Du) >> (32 - HT_BITS);
-                uint32_t owner = k;
-                for (;;) {
-                    const uint32_t o = atomicCAS(&ht[hs], HT_EMPTY, k);
-                    if (o == HT_EMPTY) break;                                   // the slot is mine: I own the key
-                    const uint4 ko = pool_item[o];
-                    if (ko.x == it.x && ko.y == it.y && ko.z == it.z) { owner = o; break; }
-                    hs = (hs + 1u) & (HT - 1u);
-                }
-                atomicAdd(&pool_item[owner].w, cw);
-                atomicMin(reinterpret_cast<unsigned long long *>(&pool_pay[owner]), ord);
-                atomicMin(&pool_pay[owner].z, lo);
-                atomicMax(&pool_pay[owner].w, hi);
-                dead = owner != k;
-            }
-            if (dead) pool_item[k].w = REC_DEAD;       // nobody adds to a record that owns nothing
-        };
-        uint4 it_s[CR];
-        unsigned long long ord_s[CR];
-        uint32_t lo_s[CR], hi_s[CR], cw_s[CR], cat_s[CR];
-        bool live_s[CR];
-        bool pass_r[CR];
-        bool never_r[CR];                              // a record of a junction that cannot be created
-#pragma unroll
-        for (uint32_t r = 0; r < CR; ++r) {
-            const uint32_t k = r * BT + t;
-            pass_r[r] = true;
-            never_r[r] = false;
-            if (r * BT >= total) continue;               // (block-uniform) nothing of the pool in this round
-            if (cp.combine == 2u && k < total) {
-                const uint4 it = pool_item[k];
-                const uint32_t px = pool_pay[k].x;
-                const KeyParts kp = unpack_key(it, cp.key);
-                const uint32_t m = ipx_motif_of(cp.genome, cp.skip_missing, kp.rank, kp.start, kp.end);
-                pass_r[r] = !(m & 0x300u) && ipx_record_passes((px >> 2) & 0xffu, m, IPX_SJ_CANON);
-                // Splice sites that are canonical on NEITHER strand: no record of this junction passes the filter whatever
-                // its strand, so the junction is never created and none of its records is ever counted (add_junction,
-                // junctions_extractor.cc:488-506; junction_filter_check, splice_juncs.cc:52-61) -- the record leaves no
-                // trace in the reference, and none here: it dies now instead of reaching the reduce to be dropped there.
-                // (A fetch that failed, 0x300, must still reach the reduce, which reports it.)  Round 4: G hands the sort
-                // 2.22 M records instead of 2.36 M; a highly expressed junction with a non-canonical motif is otherwise a
-                // pile-up of records that cannot be combined.
-                never_r[r] = !(m & 0x300u) && (m & IPX_MOTIF_PRESENT) && !(m & (IPX_MOTIF_CANON_P | IPX_MOTIF_CANON_RC));
-            }
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < CR; ++r) {
-            if (r * BT >= total) continue;
-            const uint32_t k = r * BT + t;
-            bool live = k < total;
-            uint4 it = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0);
-            if (live) { it = pool_item[k]; py = pool_pay[k]; }
-            const uint32_t cat = py.x & 3u;
-            if (live && never_r[r]) {                   // (category 3 or not: a record that is never counted raises nothing, junctions_extractor.cc:73-74)
-                live = false;
-                pool_item[k].w = REC_DEAD;
-            }
-            live = live && cat != 3u;
-            if (live && !pass_r[r]) {
-                live = false;
-                pool_item[k].w = IPX_CNT_ONE(cat);
-            }
-            unsigned long long ord = (unsigned long long)py.x | ((unsigned long long)py.y << 32);
-            // a record that an earlier combine of this tile made of several brings their counts along
-            uint32_t lo = py.z, hi = py.w, cw = (recombine && it.w) ? it.w : IPX_CNT_ONE(cat);
-            if (recombine) {
-                if (live) pool_item[k].w = 0;             // the owners' count words start from nothing again
-                it_s[r] = it; lo_s[r] = lo; hi_s[r] = hi; cw_s[r] = cw; ord_s[r] = ord; live_s[r] = live; cat_s[r] = cat;
-                continue;
-            }
-            fold_and_insert(k, it, cat, ord, lo, hi, cw, live);
-        }
-        if (recombine) {                                   // (uniform: the caller's argument)
-            __syncthreads();                               // every count word of the pool is zero now
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                if (r * BT >= total) continue;
-                fold_and_insert(r * BT + t, it_s[r], cat_s[r], ord_s[r], lo_s[r], hi_s[r], cw_s[r], live_s[r]);
-            }
-        }
-        __syncthreads();
-        // survivors close ranks: position = survivors before it in pool order
-        uint32_t pos_r[CR];
-        bool live_r[CR];
-#pragma unroll
-        for (uint32_t r = 0; r < CR; ++r) {
-            const uint32_t k = r * BT + t;
-            live_r[r] = k < total && pool_item[k].w != REC_DEAD;
-            const unsigned long long m = ipx_ballot(live_r[r]);
-            pos_r[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (lane == 0) live_n[r][wave] = (uint32_t)__popcll(m);
-        }
-        __syncthreads();
-        uint32_t n_out = 0;
-#pragma unroll
-        for (uint32_t r = 0; r < CR; ++r)
-#pragma unroll
-            for (uint32_t w = 0; w < NW; ++w) {
-                const uint32_t c = live_n[r][w];
-#pragma unroll
-                for (uint32_t r2 = 0; r2 < CR; ++r2)
-                    if (r < r2 || (r == r2 && w < wave)) pos_r[r2] += c;
-                n_out += c;
-            }
-        if (!final_pass) {
-            // make room: survivors move to the front of the pool, the table is emptied, the tile goes on
-            uint4 it2[CR], py2[CR];
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r) {
-                const uint32_t k = r * BT + t;
-                if (live_r[r]) { it2[r] = pool_item[k]; py2[r] = pool_pay[k]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t r = 0; r < CR; ++r)
-                if (live_r[r]) { pool_item[pos_r[r]] = it2[r]; pool_pay[pos_r[r]] = py2[r]; }
-            if (t == 0) {
-                pool_n = n_out;
-                merged_acc += total - n_out;
-            }
-            __syncthreads();
-            return;
-        }
-        // (where the records go: read from the argument block here, see ShortArgs)
-        const ShortArgsPtr ka = fresh_args();
-        const uint32_t ka_stripes = ka->p.n_stripes;
-        const uint64_t ka_base = ka->p.base, ka_capacity = ka->capacity;
-        const DigitSpec ka_first = load_arg(&ka->p.first);
-        uint4 *const ka_items = ka->items, *const ka_pays = ka->pays;
-        uint32_t *const ka_cnts = ka->cnts;
-        uint8_t *const ka_digs = ka->digs;
-        auto index_of = [&](uint64_t i) -> uint64_t {                      // append_index
-            if (!ka_stripes) return i;
-            const uint64_t chunk = (i >> IPX_STRIPE_CHUNK_BITS) * IPX_STRIPES + stripe;
-            return ka_base + ((chunk << IPX_STRIPE_CHUNK_BITS) | (i & ((1u << IPX_STRIPE_CHUNK_BITS) - 1)));
-        };
-        if (t == 0) {
-            Counters *const ka_counters = ka->counters;
-            unsigned long long *ctr = ka_stripes ? reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ka_counters) + IPX_CNT_STRIPE0 + 128 * stripe)
-                                                 : &ka_counters->n_records;
-            tile_slot = n_out ? atomicAdd(ctr, (unsigned long long)n_out) : 0ull;
-            merged_acc += total - n_out;
-        }
-        __syncthreads();
-        const uint64_t slot = tile_slot;
-#pragma unroll
-        for (uint32_t r = 0; r < CR; ++r) {
-            const uint32_t k = r * BT + t;
-            const uint64_t idx = index_of(slot + pos_r[r]);
-            if (live_r[r] && idx < ka_capacity) {
-                uint4 it = pool_item[k];
-                ka_cnts[idx] = it.w;
-                it.w = (uint32_t)idx;
-                ka_items[idx] = it;
-                ka_pays[idx] = pool_pay[k];
-                ka_digs[idx] = (uint8_t)ipx_digit_of(it, ka_first);
-                kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
-                kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
-            }
-        }
-    };
-
-    // the tile's records -> record arrays (total <= POOL)
-    auto store_pool = [&](const uint32_t total, const uint32_t comb, const bool recombined) {
-        if (!comb) {                                       // (uniform: a kernel argument masked with the tile number)
-            const ShortArgsPtr ka = fresh_args();
-            const ScanParams kp = load_arg(&ka->p);
-            uint4 *const ka_items = ka->items, *const ka_pays = ka->pays;
-            uint32_t *const ka_cnts = ka->cnts;
-            uint8_t *const ka_digs = ka->digs;
-            const uint64_t ka_capacity = ka->capacity;
-            if (t == 0) tile_slot = total ? atomicAdd(append_counter(ka->counters, kp, stripe), (unsigned long long)total) : 0ull;
-            __syncthreads();
-            const uint64_t slot = tile_slot;
-            for (uint32_t k = t; k < total; k += BT) {
-                const uint64_t idx = append_index(kp, stripe, slot + k);
-                if (idx < ka_capacity) {
-                    uint4 it = pool_item[k];
-                    it.w = (uint32_t)idx;
-                    ka_items[idx] = it;
-                    const uint4 py = pool_pay[k];
-                    ka_pays[idx] = py;
-                    ka_cnts[idx] = IPX_CNT_ONE(py.x & 3u);
-                    ka_digs[idx] = (uint8_t)ipx_digit_of(it, kp.first);
-                    kb.o0 |= it.x; kb.o1 |= it.y; kb.o2 |= it.z;
-                    kb.a0 &= it.x; kb.a1 &= it.y; kb.a2 &= it.z;
-                }
-            }
-        } else {
-            combine_pool(total, true, recombined);
-        }
-    };
-
-    // ---- the walks.  An alignment without a closed form (S: 7 %, i.e. ~36 of a tile's 512) runs the select-based
-    // walk of k_scan_long, eight unrolled steps.  A wave runs the walk for all its lanes or for none, and while ONE
-    // wave walked a tile's few the block's other waves waited at the barrier: that was a third of a tile's time.  So
-    // the listed alignments WAIT, across tiles, until BT of them have come together; then every wave of the block
-    // walks 64 of them into an empty pool (at most three records from eight ops: 3 BT <= POOL, it cannot overflow),
-    // which is combined and stored like a tile's.  What phase 1 had fetched of them is fetched again (two dependent
-    // round trips per pass instead of per tile).
-    uint32_t comb = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        IPX_ST_START;
-        if (t == 0) pool_n = 0;
-        __syncthreads();
-        // does THIS tile combine?  (ScanParams::combine_mask: a launch that only probes combines one tile in sixteen)
-        comb = (p.combine_mask && ((uint32_t)tile & p.combine_mask)) ? 0u : p.combine;
-        bool recombined = false;                 // (block-uniform) an early combine made room in this tile
-        // Every alignment of the tile: the plain spliced reads "aM nN bM" (two thirds of short-read data) and
-        // "aM nN bM nN cM" (most of the rest) have closed forms -- one or two junctions, anchors a, b, c, no
-        // counters.  Everything else is only LISTED here (dx_list) and walked later, see "the walks".
-        // (the loads of all RPT rounds first: a round's two dependent round trips overlap the other's)
-        ReadCtx c_r[RPT];
-        uint32_t nc_r[RPT], off_r[RPT];
-        uint4 wb_r[RPT];
-        bool walk_r[RPT];
-        uint4 w3_r[RPT];
-        const AlnArrays aln = fresh_aln();
-        const ScanParams tp = load_arg(&fresh_args()->p);
-        const uint32_t *const cigar_ = fresh_args()->cigar, *const tail_ = fresh_args()->tail;
-        const uint64_t n_words_ = aln.n_words;
-        {
-            RawAln raw_r[RPT];
-            uint32_t rank_r[RPT];
-#pragma unroll
-            for (uint32_t r = 0; r < RPT; ++r) {
-                const uint64_t i = tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t;
-                raw_r[r] = load_raw_aln(aln, i < n ? i : n - 1);
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < RPT; ++r) pin_raw(raw_r[r]);
-#pragma unroll
-            for (uint32_t r = 0; r < RPT; ++r)
-                rank_r[r] = (!tp.rank_is_tid && tp.n_targets) ? aln.rank_of_tid[rank_index(tp, raw_r[r])] : (uint32_t)raw_r[r].tid;
-#pragma unroll
-            for (uint32_t r = 0; r < RPT; ++r)
-                read_ctx_of(tp, aln, tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t, raw_r[r], rank_r[r], c_r[r], nc_r[r], off_r[r], my_err);
-        }
-        IPX_ST_LAP(0);                      // attributes arrived (the loads' issue + first use)
-#pragma unroll
-        for (uint32_t r = 0; r < RPT; ++r) {
-            w3_r[r] = load_cigar4(cigar_, tail_, n_words_, nc_r[r] ? (uint64_t)off_r[r] : 0ull);
-            // (words 4..7 of the CIGARs that have them -- off + nc <= n_words was checked --, else the array's first: every
-            // lane loads, a load behind a branch is waited for at the branch's end)
-            wb_r[r] = load_cigar4(cigar_, tail_, n_words_, (nc_r[r] >= 5 && nc_r[r] <= 7) ? (uint64_t)off_r[r] + 4 : 0ull);
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < RPT; ++r) {
-            const ReadCtx &c = c_r[r];
-            const uint32_t nc = nc_r[r];
-            const uint4 w3 = w3_r[r];
-            const uint4 wb = wb_r[r];
-            // One clip (S or H) in front and one at the end change nothing: a clip leaves the walk in LIMBO, where it
-            // starts, and ends a right anchor exactly as the end of the alignment does (junctions_extractor.cc:306-311,
-            // 278-282) -- so "xS aM nN bM yS" and the two-junction form with clips are the closed forms of what is left
-            // without them (real short-read data: one alignment in ten is clipped).
-            const bool lead = nc >= 4 && (w3.x & 0xeu) == 4u;
-            const uint32_t e0 = lead ? w3.y : w3.x, e1 = lead ? w3.z : w3.y, e2 = lead ? w3.w : w3.z, e3 = lead ? wb.x : w3.w,
-                           e4 = lead ? wb.y : wb.x, e5 = lead ? wb.z : wb.y;
-            const uint32_t m = nc - (lead ? 1u : 0u);
-            const bool mnm = (e0 & 0xfu) == 0 && (e1 & 0xfu) == 3 && (e2 & 0xfu) == 0;
-            const bool nm2 = (e3 & 0xfu) == 3 && (e4 & 0xfu) == 0;
-            const bool plain = mnm && (m == 3 || (m == 4 && (e3 & 0xeu) == 4u));
-            const bool two = mnm && nm2 && (m == 5 || (m == 6 && (e5 & 0xeu) == 4u));
-            // up to four ops, none of them N (or one the walk throws on, :312-313): nothing to find -- the clipped and
-            // the gapped unspliced reads of real data ("90M 10S", "40M 1D 60M"), which otherwise all queue for a walk
-            const uint32_t okm = 0x1b7u;                               // M I D S H = X
-            const bool dull = nc <= 4 && ((okm >> (w3.x & 0xfu)) & (okm >> (w3.y & 0xfu)) & 1u) != 0u &&
-                              (nc < 3 || ((okm >> (w3.z & 0xfu)) & 1u) != 0u) && (nc < 4 || ((okm >> (w3.w & 0xfu)) & 1u) != 0u);
-            const bool walk_it = nc != 0 && !plain && !two && !dull;
-            // (more than 8 ops in a short-CIGAR batch: k_scan_rest's op-by-op walk)
-            const bool list_it = walk_it && nc <= 8, rest_it = walk_it && nc > 8;
-            walk_r[r] = walk_it;
-            const unsigned long long wm = ipx_ballot(list_it);
-            if (wm) {
-                const int first = __ffsll(wm) - 1;
-                uint32_t base = 0;
-                if ((int)lane == first) base = atomicAdd(&dx_n, (uint32_t)__popcll(wm));
-                base = __shfl(base, first);
-                if (list_it)
-                    dx_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))] =
-                        (uint32_t)(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t);
-            }
-            const unsigned long long dm = ipx_ballot(rest_it);
-            if (dm) {
-                const int first = __ffsll(dm) - 1;
-                uint32_t base = 0;
-                const ShortArgsPtr ka = fresh_args();
-                uint32_t *const ka_defer = ka->defer;
-                if ((int)lane == first) base = atomicAdd(defer_counter(ka->counters), (uint32_t)__popcll(dm));
-                base = __shfl(base, first);
-                if (rest_it)
-                    ka_defer[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] =
-                        (uint32_t)(tile * ((uint64_t)BT * RPT) + (uint64_t)r * BT + t);
-            }
-            // M: LIMBO -> LEFT, N: -> INTRON, M: -> RIGHT, then either finish(): one record, or N: the record,
-            // its right anchor becomes the next left anchor, -> INTRON, M: -> RIGHT, finish(): the second record
-            // (junctions_extractor.cc:208-254,278-282).  Five lengths below 2^28 cannot leave 32 bits.
-            const uint32_t a = e0 >> 4, n1 = e1 >> 4, b = e2 >> 4, n2 = e3 >> 4, c5 = e4 >> 4;
-            const bool pass1 = (plain || two) && !c.read_rejected && n1 >= tp.min_intron_length && n1 <= tp.max_intron_length &&
-                               a >= tp.min_anchor_length && b >= tp.min_anchor_length;     // junction_qc :392-397
-            const bool pass2 = two && !c.read_rejected && n2 >= tp.min_intron_length && n2 <= tp.max_intron_length &&
-                               b >= tp.min_anchor_length && c5 >= tp.min_anchor_length;
-            const unsigned long long em1 = ipx_ballot(pass1);
-            if (em1) {
-                const uint32_t slot = pool_slot(em1);
-                if (pass1 && slot < POOL) {
-                    ReadCtx cc = c;
-                    cc.pos = 0;
-                    uint4 it, pay;
-                    const Rec rr{0, (int64_t)a, (int64_t)(a + n1), (int64_t)(a + n1 + b), 0, 0, 0, 0};
-                    pack_record_rel(tp, cc, rr, (uint32_t)c.pos, 0u, it, pay);
-                    pool_item[slot] = it;
-                    pool_pay[slot] = pay;
-                }
-            }
-            const unsigned long long em2 = ipx_ballot(pass2);
-            if (em2) {
-                const uint32_t slot = pool_slot(em2);
-                if (pass2 && slot < POOL) {
-                    ReadCtx cc = c;
-                    cc.pos = 0;
-                    uint4 it, pay;
-                    const uint32_t s2 = a + n1 + b;
-                    const Rec rr{(int64_t)(a + n1), (int64_t)s2, (int64_t)(s2 + n2), (int64_t)(s2 + n2 + c5), 0, 0, 0, 0};
-                    pack_record_rel(tp, cc, rr, (uint32_t)c.pos, pass1 ? 1u : 0u, it, pay);      // ordinals count QC-passed records
-                    pool_item[slot] = it;
-                    pool_pay[slot] = pay;
-                }
-            }
-            // A tile of mostly two-junction reads emits more than the pool holds (S: 3 % of the tiles, a quarter of
-            // all records that left the scan uncombined through the second stage).  If the first half of the tile
-            // filled more than its share, fold what is there and go on in the room that makes.
-            if (r + 1 < RPT && comb) {                     // (uniform: r is the unrolled round, comb see store_pool)
-                __syncthreads();
-                const uint32_t filled = pool_n;
-                // Everybody has read the count before anybody goes on adding to it.  Without this barrier (rounds 2 and
-                // 3, found with profiles/microbench/consistency_m1.py) a thread that was late to read saw the first
-                // records of the next round already counted, and in a tile that stood right at the threshold part of the
-                // block went into combine_pool -- and its barriers -- while the rest did not: one finalize in eight of
-                // the M shard lost or garbled a tile's records.
-                __syncthreads();
-                // (uniform: `filled` is pool_n, last added to before the first of the two barriers above and not again
-                // until every thread has passed the second)
-                if (2u * filled + 64u > POOL && filled <= POOL) {
-                    combine_pool(filled, false, false);
-                    recombined = true;
-                }
-            }
-        }
-        // ---- store the tile's records; then, while enough listed alignments wait (or, after the block's last tile,
-        // any): a walk pass into the emptied pool, stored the same way
-        const bool last_tile = tile + gridDim.x >= n_tiles;
-        bool from_walk = false;
-        uint32_t w_from = 0, w_take = 0;
-        for (;;) {
-            __syncthreads();
-            if (from_walk) IPX_ST_LAP(2); else IPX_ST_LAP(1);
-            // (uniform: pool_n was last added to before the barrier at the top of this loop -- phase 1's records, an early
-            // combine's result, or a walk pass's -- and is next written by thread 0 after the barrier that follows the store,
-            // at the start of a walk pass or of the next tile; `recombined` is set under the uniform early-combine test)
-            const uint32_t total = pool_n;
-            if (total <= POOL) {
-                store_pool(total, comb, recombined);
-            } else {
-                // the pool overflowed: nothing of it is stored, the tile's alignments go to k_scan_rest (those of more
-                // than 8 ops are on its list already, those that wait for a walk pass stay where they are).  A walk
-                // pass cannot overflow (see "the walks"); if it ever did, its alignments would go the same way.
-                const uint64_t tile_base = tile * ((uint64_t)BT * RPT);
-                const ShortArgsPtr ka = fresh_args();
-                const uint32_t *const a_nc_ = ka->a_nc;
-                uint32_t *const ka_defer = ka->defer;
-                const uint64_t n_ = ka->n;
-                uint32_t mine_n = 0;
-                if (from_walk) {
-                    mine_n = t < w_take ? 1u : 0u;
-                } else {
-#pragma unroll
-                    for (uint32_t r = 0; r < RPT; ++r) {
-                        const uint64_t i = tile_base + (uint64_t)r * BT + t;
-                        mine_n += (i < n_ && !walk_r[r] && a_nc_[i] <= 8) ? 1u : 0u;
-                    }
-                }
-                // block-wide exclusive prefix of mine_n (NW waves)
-                uint32_t incl = mine_n;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t x = __shfl_up(incl, o);
-                    if ((int)lane >= o) incl += x;
-                }
-                if (lane == 63) kb_s[wave][0] = incl;
-                __syncthreads();
-                uint32_t before = 0, all = 0;
-                for (uint32_t w = 0; w < NW; ++w) { const uint32_t sw = kb_s[w][0]; if (w < wave) before += sw; all += sw; }
-                if (t == 0) tile_slot = all ? atomicAdd(defer_counter(ka->counters), all) : 0u;
-                __syncthreads();
-                uint32_t at = (uint32_t)tile_slot + before + incl - mine_n;
-                if (from_walk) {
-                    if (t < w_take) ka_defer[at] = dx_list[w_from + t];
-                } else {
-#pragma unroll
-                    for (uint32_t r = 0; r < RPT; ++r) {
-                        const uint64_t i = tile_base + (uint64_t)r * BT + t;
-                        if (i < n_ && !walk_r[r] && a_nc_[i] <= 8) ka_defer[at++] = (uint32_t)i;
-                    }
-                }
-            }
-            __syncthreads();
-            IPX_ST_LAP(3);                      // combine + reservation + copy-out
-            // (uniform: dx_n was last added to in phase 1, before the barrier at the top of this loop, or set by thread 0
-            // between the two barriers below; it is read here after a barrier and not written again before the next one.
-            // last_tile: blockIdx, gridDim and the tile counter)
-            const uint32_t have = dx_n;
-            if (!(have >= BT || (last_tile && have != 0u))) break;
-            const uint32_t take = have < BT ? have : BT, from = have - take;
-            w_from = from; w_take = take;
-            from_walk = true;
-            recombined = false;
-            __syncthreads();
-            if (t == 0) { pool_n = 0; dx_n = from; }
-            __syncthreads();
-                if (wave * 64u < take) {       // (wave-uniform, and no block barrier inside: a wave without alignments to walk skips to the loop's top)
-                    const bool mine = t < take;
-                    const uint64_t i = mine ? dx_list[from + t] : 0u;
-                    ReadCtx c;
-                    uint32_t nc = 0, off = 0;
-                    unsigned long long seen = IPX_ERRW_NONE;     // gate errors were reported when the alignment was listed
-                    const AlnArrays waln = fresh_aln();
-                    const ScanParams wp = load_arg(&fresh_args()->p);
-                    const uint32_t *const wcigar = fresh_args()->cigar, *const wtail = fresh_args()->tail;
-                    load_read_ctx(wp, waln, i, c, nc, off, seen);
-                    if (!mine) nc = 0;
-                    const bool small = nc != 0 && nc <= 8;
-                    const uint4 wa = load_cigar4(wcigar, wtail, waln.n_words, small ? (uint64_t)off : 0ull);
-                    // (a lane without a CIGAR of five to eight words reads the array's first words)
-                    const uint4 wb = load_cigar4(wcigar, wtail, waln.n_words, (small && nc > 4) ? (uint64_t)off + 4 : 0ull);
-                const uint32_t pos32 = (uint32_t)c.pos;
-
-                bool active = small, pending = false, fin = false;
-                uint32_t left = small ? nc : 0u;
-                uint32_t state = ST_LIMBO;
-                uint32_t tp = 0, as = 0, is = 0, ie = 0, ae = 0;
-                uint32_t lmm = 0, rmm = 0, lind = 0, rind = 0, cur_indel = 0, ordinal = 0;
-                uint32_t s_as = 0, s_is = 0, s_ie = 0, s_ae = 0, s_l = 0, s_r = 0;
-
-                auto snap_ok = [&]() {
-                    const uint32_t q_as = fin ? as : s_as, q_is = fin ? is : s_is, q_ie = fin ? ie : s_ie, q_ae = fin ? ae : s_ae;
-                    const uint32_t q_l = fin ? lmm + lind : s_l, q_r = fin ? rmm + rind : s_r;
-                    const uint32_t ilen = q_ie - q_is;
-                    return !c.read_rejected && ilen >= wp.min_intron_length && ilen <= wp.max_intron_length &&
-                           (uint64_t)(q_is - q_as) >= (uint64_t)q_l + wp.min_anchor_length &&
-                           (uint64_t)(q_ae - q_ie) >= (uint64_t)q_r + wp.min_anchor_length;
-                };
-                // QC, pack and store the waiting snapshots of the whole wave
-                auto drain = [&]() {
-                    const bool pass = pending && snap_ok();
-                    const unsigned long long em = ipx_ballot(pass);
-                    if (em) {
-                        const uint32_t slot = pool_slot(em);
-                        if (pass) {
-                            if (slot < POOL) {
-                                ReadCtx cc = c;
-                                cc.pos = 0;
-                                uint4 it, pay;
-                                const Rec rr{(int64_t)(fin ? as : s_as), (int64_t)(fin ? is : s_is), (int64_t)(fin ? ie : s_ie),
-                                             (int64_t)(fin ? ae : s_ae), 0, 0, 0, 0};
-                                pack_record_rel(wp, cc, rr, pos32, ordinal, it, pay);
-                                pool_item[slot] = it;
-                                pool_pay[slot] = pay;
-                            }
-                            ++ordinal;
-                        }
-                    }
-                    pending = false;
-                    fin = false;
-                };
-                auto step = [&](uint32_t w) {
-                    const bool run = active && left != 0;
-                    const uint32_t op = w & 0xfu, len = w >> 4;
-                    const uint32_t cls = (uint32_t)(0x0000000110882441ull >> (op * 4u)) & 0xfu;
-                    const bool c_m = run && cls == 1u, c_n = run && cls == 2u, c_id = run && cls == 4u, c_sh = run && cls == 8u;   // one-hot
-                    const bool in_l = state == ST_LEFT, in_r = state == ST_RIGHT;
-                    lind += (c_id && in_l) ? len : 0u;
-                    rind += (c_id && in_r) ? len : 0u;
-                    const uint32_t indel2 = cur_indel + len;
-                    const bool over = c_id && indel2 > wp.max_anchor_indel_size;
-                    const bool trig = in_r && (c_n || c_sh || over);
-                    const bool last = run && left == 1;
-                    if (ipx_ballot(pending && (trig || last))) drain();
-                    s_as = trig ? as : s_as; s_is = trig ? is : s_is; s_ie = trig ? ie : s_ie; s_ae = trig ? ae : s_ae;
-                    s_l = trig ? lmm + lind : s_l; s_r = trig ? rmm + rind : s_r;
-                    pending = pending || trig;
-                    const uint32_t tpn = tp + len;
-                    const bool adv = c_m || c_n || (c_id && op == 2);
-                    const bool bad = run && cls == 0;
-                    if (ipx_ballot(bad)) {
-                        if (bad) {                                              // :312-313: the exception ends the read
-                            const uint32_t ch = (op == 6) ? 'P' : (op == 9 ? 'B' : '?');
-                            const uint32_t ord_e = ordinal + ((pending && snap_ok()) ? 1u : 0u);
-                            const unsigned long long e = (c.read_index << IPX_ORD_SHIFT_READ) |
-                                                         ((unsigned long long)ord_e << IPX_ORD_SHIFT_ORDINAL) |
-                                                         (IPX_ERRK_CIGAR << 8) | ch;
-                            my_err = e < my_err ? e : my_err;
-                        }
-                    }
-                    const bool n_r = c_n && in_r, n_lr = c_n && (in_l || in_r);
-                    const bool m_limbo = c_m && state == ST_LIMBO, m_intron = c_m && state == ST_INTRON;
-                    const uint32_t as2 = n_r ? ie : (m_limbo ? tp : as);
-                    const uint32_t ie2 = n_lr ? tpn : (m_intron ? tp : ie);
-                    is = n_lr ? tp : is;
-                    as = as2;
-                    ie = ie2;
-                    ae = c_m ? tpn : ae;
-                    uint32_t lmm2 = n_r ? rmm : (m_limbo ? 0u : lmm);
-                    uint32_t rmm2 = (n_r || m_limbo) ? 0u : rmm;
-                    lind = n_r ? rind : lind;
-                    rind = n_r ? 0u : rind;
-                    state = n_lr ? ST_INTRON : m_limbo ? ST_LEFT : m_intron ? ST_RIGHT : (over || c_sh) ? ST_LIMBO : state;
-                    const bool x = c_m && op == 8;
-                    lmm2 += (x && state == ST_LEFT) ? len : 0u;
-                    rmm2 += (x && state == ST_RIGHT) ? len : 0u;
-                    lmm = lmm2;
-                    rmm = rmm2;
-                    cur_indel = (c_m || c_n) ? 0u : (c_id ? indel2 : cur_indel);
-                    tp = adv ? tpn : tp;
-                    fin = fin || (last && !bad && state == ST_RIGHT);   // finish(): never together with `trig`; kept until the drain
-                    pending = pending || fin;
-                    left -= run ? 1u : 0u;
-                    active = run && !last && !bad;
-                };
-                step(wa.x);
-                step(wa.y);
-                if (ipx_ballot(active)) step(wa.z);
-                if (ipx_ballot(active)) step(wa.w);
-                if (ipx_ballot(active)) step(wb.x);
-                if (ipx_ballot(active)) step(wb.y);
-                if (ipx_ballot(active)) step(wb.z);
-                if (ipx_ballot(active)) step(wb.w);
-                if (ipx_ballot(pending)) drain();
-            }
-        }
-#ifdef IPX_SCAN_STATS
-        ++st_tiles;
-#endif
-    }
-    {
-        unsigned long long e = my_err;
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(e, d);
-            e = o < e ? o : e;
-        }
-        if (lane == 0 && e != IPX_ERRW_NONE) atomicMin(&fresh_args()->counters->err_word, e);
-    }
-#ifdef IPX_SCAN_STATS
-    if (t == 0 && (blockIdx.x % 199) == 0 && st_tiles)
-        printf("block %u: %u tiles; cycles per tile: attributes %llu, phase 1 %llu, walks %llu, combine + copy-out %llu\n", blockIdx.x,
-               st_tiles, st_ph[0] / st_tiles, st_ph[1] / st_tiles, st_ph[2] / st_tiles, st_ph[3] / st_tiles);
-#endif
-    Counters *const counters_ = fresh_args()->counters;
-    if (t == 0 && merged_acc)
-        atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters_) + IPX_CNT_MERGED), merged_acc);
-    uint32_t v[6] = {kb.o0, kb.o1, kb.o2, kb.a0, kb.a1, kb.a2};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-            const uint32_t o = __shfl_xor(v[k], dlt);
-            v[k] = (k < 3) ? (v[k] | o) : (v[k] & o);
-        }
-        if (lane == 0) kb_s[wave][k] = v[k];
-    }
-    __syncthreads();
-    if (t < 6) {
-        uint32_t o = 0, a = ~0u;
-        for (uint32_t w = 0; w < NW; ++w) { o |= kb_s[w][t]; a &= kb_s[w][t]; }
-        if (t < 3) {
-            if (o) atomicOr(&counters_->key_or[t], o);
-        } else {
-            if (a != ~0u) atomicAnd(&counters_->key_and[t - 3], a);
-        }
-    }
-}
-
 #include "ipx_scan_short.inc"
 
 // ---- what k_scan_short left out ------------------------------------------------------------------
@@ -2024,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, co
     __shared__ uint32_t kb_s[4][6];
     KeyBits kb{0u, 0u, 0u, ~0u, ~0u, ~0u};
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t stripe = my_stripe(p);
+    const uint32_t stripe = my_stripe(p, wave);
     unsigned long long my_err = IPX_ERRW_NONE;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t e0 = ((uint64_t)blockIdx.x * 4 + wave) * 64; e0 < n_def; e0 += stride) {
@@ -2080,101 +1294,129 @@ __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, co
 }
 
 // ---- closing the gaps of a striped launch ---------------------------------------------------------
-// After a striped scan the launch's records sit in eight interleaved stripes behind `base`, every stripe
-// filled up to its own count: all positions below the shortest stripe's last full round of chunks are
-// taken, the rest of the range has holes.  k_close_find lists the holes below base + n and the records at
-// or above it (equally many), k_close_move pairs them off, k_close_finish publishes base + n as the
-// record count and zeroes the stripe counters for the next launch.  A launch that ran out of capacity
-// publishes the extent it would have needed instead (the caller grows the arrays and repeats the scan).
-struct StripeState {
-    unsigned long long n, extent, window_lo;
-};
-__device__ __forceinline__ unsigned long long stripe_count(const Counters *counters, uint32_t k) {
-    return *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(counters) + IPX_CNT_STRIPE0 + 128 * k);
-}
+// After a striped scan the launch's records sit in IPX_STRIPES interleaved stripes behind `base`, every stripe filled up
+// to its own count: all positions below the shortest stripe's last full round of chunks are taken, the rest of the
+// range -- the WINDOW -- has holes.  k_close moves the records at or above base + n into the holes below it (equally
+// many), publishes base + n as the record count and zeroes the stripe counters for the next launch.  Rounds 1-4 did
+// this with three kernels that scanned the window position by position (find / move / finish, 16 us).  But the holes
+// have a closed form: a chunk of the window is taken up to its stripe's count and free behind it, so a block needs only
+// a prefix sum over the window's CHUNKS (<= two per thread) to know where the i-th hole and the i-th record to move
+// lie; every block works that out for itself and moves its share of the pairs, nothing is listed, and the block that
+// finishes last (a counter) publishes.  A launch that ran out of capacity publishes the extent it would have needed
+// instead (the caller grows the arrays and repeats the scan); a window of more than CLOSE_MAX_CHUNKS chunks (stripes
+// that filled very unevenly) raises Counters::pad[1] and the caller repeats the scan without stripes.
+constexpr uint32_t CLOSE_BT = 1024, CLOSE_BLOCKS = 64;
+constexpr uint32_t CLOSE_MAX_CHUNKS = 2 * CLOSE_BT;
+constexpr uint32_t CHUNK = 1u << IPX_STRIPE_CHUNK_BITS;
 
-__device__ __forceinline__ StripeState stripe_state(const Counters *counters) {
-    StripeState st;
-    st.n = 0;
-    st.extent = 0;
-    unsigned long long rounds = ~0ull;
+__global__ __launch_bounds__(CLOSE_BT) void k_close(Counters *counters, uint64_t base, uint64_t capacity,
+                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
+                                                    uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs) {
+    __shared__ unsigned long long cnt_s[IPX_STRIPES];
+    __shared__ uint32_t hpre[CLOSE_MAX_CHUNKS + 1], tpre[CLOSE_MAX_CHUNKS + 1];      // holes / records to move before chunk c
+    __shared__ uint32_t wsum_h[CLOSE_BT / 64], wsum_t[CLOSE_BT / 64];
+    __shared__ uint32_t last_s;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (t < IPX_STRIPES)
+        cnt_s[t] = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(counters) + IPX_CNT_STRIPE0 + 128 * t);
+    __syncthreads();
+    unsigned long long n = 0, extent = 0, rounds = ~0ull;
     for (uint32_t k = 0; k < IPX_STRIPES; ++k) {
-        const unsigned long long c = stripe_count(counters, k);
-        st.n += c;
+        const unsigned long long c = cnt_s[k];
+        n += c;
         if (c) {
             const unsigned long long last = c - 1;
-            const unsigned long long end = ((((last >> IPX_STRIPE_CHUNK_BITS) * IPX_STRIPES + k) << IPX_STRIPE_CHUNK_BITS) |
-                                            (last & ((1u << IPX_STRIPE_CHUNK_BITS) - 1))) + 1;
-            st.extent = end > st.extent ? end : st.extent;
+            const unsigned long long end = ((((last >> IPX_STRIPE_CHUNK_BITS) * IPX_STRIPES + k) << IPX_STRIPE_CHUNK_BITS) | (last & (CHUNK - 1))) + 1;
+            extent = end > extent ? end : extent;
         }
         const unsigned long long full = c >> IPX_STRIPE_CHUNK_BITS;
         rounds = full < rounds ? full : rounds;
     }
-    st.window_lo = (rounds * IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS;
-    return st;
-}
-
-__global__ __launch_bounds__(256) void k_close_find(Counters *counters, uint64_t base, uint64_t capacity,
-                                                    unsigned long long *__restrict__ holes,
-                                                    unsigned long long *__restrict__ tails, uint64_t list_cap) {
-    const StripeState st = stripe_state(counters);
-    if (base + st.extent > capacity || st.extent == st.n) return;
-    unsigned long long *n_holes = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_CLOSE);
-    unsigned long long *n_tails = n_holes + 16;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p0 = st.window_lo + (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); p0 < st.extent; p0 += stride) {
-        const uint64_t pos = p0 + lane;
-        const uint64_t chunk = pos >> IPX_STRIPE_CHUNK_BITS;
-        const uint32_t k = (uint32_t)(chunk & (IPX_STRIPES - 1));
-        const uint64_t i = ((chunk / IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS) | (pos & ((1u << IPX_STRIPE_CHUNK_BITS) - 1));
-        const bool taken = pos < st.extent && i < stripe_count(counters, k);      // (a per-lane index into a register array would live in scratch)
-        const bool hole = pos < st.n && !taken, tail = pos >= st.n && taken;
-        const unsigned long long hm = ipx_ballot(hole), tm = ipx_ballot(tail);
-        if (hm) {
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(n_holes, (unsigned long long)__popcll(hm));
-            at = __shfl(at, 0) + (unsigned long long)__popcll(hm & ((1ull << lane) - 1ull));
-            if (hole && at < list_cap) holes[at] = pos;
+    const unsigned long long window_lo = (rounds * IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS;
+    // (block-uniform, like everything computed from cnt_s)
+    const bool no_room = base + extent > capacity;
+    const uint64_t n_chunks = (extent - window_lo + CHUNK - 1) >> IPX_STRIPE_CHUNK_BITS;
+    const bool too_wide = !no_room && extent != n && n_chunks > CLOSE_MAX_CHUNKS;
+    if (!no_room && !too_wide && extent != n) {
+        // chunk c of the window: positions P0 .. P0 + CHUNK, taken up to P0 + tk
+        uint32_t nh[2], nt[2];
+#pragma unroll
+        for (uint32_t e = 0; e < 2; ++e) {
+            const uint64_t c = (uint64_t)t * 2 + e;
+            nh[e] = nt[e] = 0;
+            if (c < n_chunks) {
+                const uint64_t P0 = window_lo + (c << IPX_STRIPE_CHUNK_BITS);
+                const uint64_t r = rounds + c / IPX_STRIPES, L0 = r << IPX_STRIPE_CHUNK_BITS;
+                const unsigned long long ck = cnt_s[c % IPX_STRIPES];
+                const uint64_t tk = ck <= L0 ? 0 : (ck - L0 >= CHUNK ? CHUNK : ck - L0);
+                const uint64_t free_lo = P0 + tk, free_hi = P0 + CHUNK < n ? P0 + CHUNK : n;       // free positions below n
+                nh[e] = free_hi > free_lo ? (uint32_t)(free_hi - free_lo) : 0u;
+                const uint64_t mv_lo = P0 > n ? P0 : n;                                              // taken positions at or above n
+                nt[e] = P0 + tk > mv_lo ? (uint32_t)(P0 + tk - mv_lo) : 0u;
+            }
         }
-        if (tm) {
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(n_tails, (unsigned long long)__popcll(tm));
-            at = __shfl(at, 0) + (unsigned long long)__popcll(tm & ((1ull << lane) - 1ull));
-            if (tail && at < list_cap) tails[at] = pos;
+        uint32_t ih = nh[0] + nh[1], it = nt[0] + nt[1];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t xh = __shfl_up(ih, o), xt = __shfl_up(it, o);
+            if ((int)lane >= o) { ih += xh; it += xt; }
+        }
+        if (lane == 63) { wsum_h[wave] = ih; wsum_t[wave] = it; }
+        __syncthreads();
+        uint32_t bh = 0, bt = 0, n_pairs = 0;
+        for (uint32_t w = 0; w < CLOSE_BT / 64; ++w) {
+            if (w < wave) { bh += wsum_h[w]; bt += wsum_t[w]; }
+            n_pairs += wsum_h[w];
+        }
+        const uint32_t eh = bh + ih - nh[0] - nh[1], et = bt + it - nt[0] - nt[1];
+        hpre[2 * t] = eh; hpre[2 * t + 1] = eh + nh[0];
+        tpre[2 * t] = et; tpre[2 * t + 1] = et + nt[0];
+        if (t == CLOSE_BT - 1) { hpre[CLOSE_MAX_CHUNKS] = eh + nh[0] + nh[1]; tpre[CLOSE_MAX_CHUNKS] = et + nt[0] + nt[1]; }
+        __syncthreads();
+        // the i-th hole, the i-th record to move: the last chunk whose prefix is <= i
+        auto chunk_of = [&](const uint32_t *pre, uint32_t i) {
+            uint32_t lo = 0, hi = CLOSE_MAX_CHUNKS;                        // pre[lo] <= i < pre[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (pre[mid] <= i) lo = mid; else hi = mid;
+            }
+            return lo;
+        };
+        for (uint32_t i = blockIdx.x * CLOSE_BT + t; i < n_pairs; i += gridDim.x * CLOSE_BT) {
+            const uint32_t ch = chunk_of(hpre, i), ct = chunk_of(tpre, i);
+            uint64_t dst, src;
+            {
+                const uint64_t P0 = window_lo + ((uint64_t)ch << IPX_STRIPE_CHUNK_BITS);
+                const uint64_t L0 = (rounds + ch / IPX_STRIPES) << IPX_STRIPE_CHUNK_BITS;
+                const unsigned long long ck = cnt_s[ch % IPX_STRIPES];
+                const uint64_t tk = ck <= L0 ? 0 : (ck - L0 >= CHUNK ? CHUNK : ck - L0);
+                dst = base + P0 + tk + (i - hpre[ch]);
+            }
+            {
+                const uint64_t P0 = window_lo + ((uint64_t)ct << IPX_STRIPE_CHUNK_BITS);
+                src = base + (P0 > n ? P0 : n) + (i - tpre[ct]);
+            }
+            uint4 v = items[src];
+            v.w = (uint32_t)dst;
+            items[dst] = v;
+            pays[dst] = pays[src];
+            cnts[dst] = cnts[src];
+            digs[dst] = digs[src];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_close_move(const Counters *counters, uint64_t base,
-                                                    const unsigned long long *__restrict__ holes,
-                                                    const unsigned long long *__restrict__ tails, uint64_t list_cap,
-                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                    uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs) {
-    const unsigned long long n = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(counters) + IPX_CNT_CLOSE);
-    if (n > list_cap) return;                       // reported by k_close_finish
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t src = base + tails[i], dst = base + holes[i];
-        uint4 it = items[src];
-        it.w = (uint32_t)dst;
-        items[dst] = it;
-        pays[dst] = pays[src];
-        cnts[dst] = cnts[src];
-        digs[dst] = digs[src];
+    // the block that finishes last publishes and resets (every block has read the stripe counters by then)
+    __syncthreads();
+    unsigned int *const done = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(counters) + IPX_CNT_CLOSE_DONE);
+    if (t == 0) last_s = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!last_s) return;
+    if (t == 0) {
+        counters->n_records = no_room ? base + extent : base + n;            // out of room: what it would take
+        if (too_wide) counters->pad[1] = 1;                                  // repeat without stripes
+        *done = 0;
     }
-}
-
-__global__ void k_close_finish(Counters *counters, uint64_t base, uint64_t capacity, uint64_t list_cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const StripeState st = stripe_state(counters);
-    unsigned long long *n_holes = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_CLOSE);
-    if (base + st.extent > capacity) counters->n_records = base + st.extent;     // out of room: what it would take
-    else counters->n_records = base + st.n;
-    if (*n_holes > list_cap) counters->pad[1] = 1;                               // lists too short: repeat without stripes
-    for (uint32_t k = 0; k < IPX_STRIPES; ++k)
-        *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_STRIPE0 + 128 * k) = 0;
-    n_holes[0] = 0;
-    n_holes[16] = 0;
+    if (t < IPX_STRIPES)
+        *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_STRIPE0 + 128 * t) = 0;
 }
 
 }  // namespace
@@ -2184,7 +1426,6 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                            uint64_t capacity, Counters *counters, uint64_t n_records_before,
                            unsigned long long *close_ws, uint64_t close_cap, uint32_t *defer, uint32_t rest_hint) {
     if (b.n_alignments == 0) return hipSuccess;
-    // short CIGARs: 2 alignments per thread and tile (512 per atomic), records staged in LDS; long ones: 1
     // Which kernel: the short-CIGAR kernel walks at most 8 ops per alignment itself and hands longer ones to a
     // slow second stage, so it is for batches where those are rare.  Measured on 2 M random CIGARs
     // (profiles/mid_cigar_timing.py): 2-8 ops short 0.12 ms / long 0.16 ms; 4-12 ops 0.37 / 0.18; 6-16 ops
@@ -2194,24 +1435,11 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
     const long sma_v = sma ? atol(sma) : 0;
     const uint64_t short_max_avg = (uint64_t)(sma_v >= 1 && sma_v <= 16 ? sma_v : 6);
     const bool short_reads = b.n_cigar_words <= short_max_avg * b.n_alignments || b.n_cigar_words < 8;
-    // short CIGARs: blocks of 256 threads, 2 alignments per thread (tile = 512 alignments, pool of 768 records).
-    // With 4 waves per SIMD the 128-thread block won (more tiles in flight hide a tile's chain of latencies:
-    // loads, walk, one reservation, copy-out); at 5 waves per SIMD the kernel is as much instruction- as
-    // latency-bound and the larger tile packs the alignments that need the walk into fuller waves (a third of
-    // S's alignments: 85 of 256 fill 1.3 waves, 170 of 512 fill 2.7): 0.287 -> 0.263 ms.  The grid is what is
-    // resident at once (96 VGPRs, 5 waves per SIMD), every block loops over tiles: fewer blocks leave CUs idle,
-    // more add a ragged last round and more end-of-block atomics on the key masks.
-    // (rounds 1-3 could pick 64- and 128-thread blocks through IPX_SHORT_BT; both measured slower, retired in round 4)
-    constexpr uint32_t short_bt = 256;
     static const uint32_t n_cus = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         return (uint32_t)cus;
     }();
-    const uint64_t per_tile = short_reads ? 2ull * short_bt : 256;
-    uint64_t blocks = ipx_div_up(b.n_alignments, per_tile);
-    const uint64_t resident = (uint64_t)n_cus * (1280u / short_bt);
-    if (blocks > resident) blocks = resident;
     uint32_t *tail = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(counters) + IPX_CNT_TAIL);
     ipx_prof_pre(s, IPXK_SCAN);
     hipLaunchKernelGGL(k_cigar_tail, dim3(1), dim3(64), 0, s, b.cigar, b.n_cigar_words, tail,
@@ -2219,9 +1447,8 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counters) + IPX_CNT_MERGED));
     // stripes pay once many blocks queue on the record counter
     p.base = n_records_before;
-    p.n_stripes = (blocks >= 64 && close_ws && close_cap) ? IPX_STRIPES : 0;
-    static const bool short_old = [] { const char *e = getenv("IPX_SHORT_OLD"); return e && e[0] == '1'; }();
-    if (short_reads && !short_old) {
+    p.n_stripes = 0;
+    if (short_reads) {
         // k_scan_short3 (ipx_scan_short.inc): a wave per 128 alignments, six blocks of four waves per CU
         uint64_t blocks3 = ipx_div_up(b.n_alignments, (uint64_t)S3_WT * S3_NW);
         const uint64_t resident3 = (uint64_t)n_cus * 6u;
@@ -2240,10 +1467,7 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         } else {
             hipLaunchKernelGGL((k_scan_short3<0>), dim3((uint32_t)blocks3), dim3(64 * S3_NW), 0, s, a);
         }
-    } else if (short_reads)
-        hipLaunchKernelGGL((k_scan_short<2, 768, 256>), dim3((uint32_t)blocks), dim3(256), 0, s, p, b.n_alignments,
-                           b.n_cigar_words, b.base_read_index, b.tid, b.pos, b.flag, b.xs, b.nh, b.cigar_off, b.n_cigar,
-                           b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters, defer);
+    }
     else {
         // long CIGARs: waves work through ranges of >= 64 alignments
         constexpr uint32_t min_range = 64;
@@ -2284,12 +1508,8 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         hipLaunchKernelGGL(k_scan_rest, dim3(rest_blocks), dim3(256), 0, s, p, aln, b.cigar, defer, items, pays, cnts, digs, capacity,
                            counters);
     }
-    if (p.n_stripes) {
-        unsigned long long *holes = close_ws, *tails = close_ws + close_cap;
-        hipLaunchKernelGGL(k_close_find, dim3(256), dim3(256), 0, s, counters, p.base, capacity, holes, tails, close_cap);
-        hipLaunchKernelGGL(k_close_move, dim3(64), dim3(256), 0, s, counters, p.base, holes, tails, close_cap, items, pays, cnts, digs);
-        hipLaunchKernelGGL(k_close_finish, dim3(1), dim3(64), 0, s, counters, p.base, capacity, close_cap);
-    }
+    if (p.n_stripes)
+        hipLaunchKernelGGL(k_close, dim3(CLOSE_BLOCKS), dim3(CLOSE_BT), 0, s, counters, p.base, capacity, items, pays, cnts, digs);
     ipx_prof_mark(s, IPXK_SCAN);
     return hipGetLastError();
 }

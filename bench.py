@@ -41,6 +41,28 @@ KEYS = ("tid", "pos", "flag", "xs", "nh", "cigar_off", "n_cigar", "cigar")
 DEFAULT_READS = {"S": 10_000_000, "G": 10_000_000, "L": 2_000_000}     # BASELINE.json configs[1..3]
 
 
+
+class LookAhead:
+    """A scan of the NEXT batch on a helper thread (the exchange path's two handles take turns).  What the thread raises
+    is kept and raised again where it is joined: a scan that failed must not leave a cleared or half-filled handle to the
+    next step's exchange (advisor, round 4)."""
+    def __init__(self, fn, arg):
+        import threading
+        self.exc = None
+        def body():
+            try:
+                fn(arg)
+            except BaseException as e:      # noqa: BLE001 -- re-raised by join()
+                self.exc = e
+        self.th = threading.Thread(target=body)
+        self.th.start()
+
+    def join(self):
+        self.th.join()
+        if self.exc is not None:
+            exc, self.exc = self.exc, None
+            raise exc
+
 def make_workload(kind, reads, seed):
     from intronprospector_amd import synth
     if kind == "S":
@@ -522,7 +544,6 @@ def run_m(args, rank, world, local_rank):
                 base += na
 
         def step(self):
-            import threading
             if self.ex2 is None:
                 self.scan(self.ex)
             else:
@@ -533,9 +554,7 @@ def run_m(args, rank, world, local_rank):
                     self.cur, th = self.ahead
                     th.join()
                 nxt = self.ex2 if self.cur is self.ex else self.ex
-                th = threading.Thread(target=self.scan, args=(nxt,))
-                th.start()
-                self.ahead = (nxt, th)
+                self.ahead = (nxt, LookAhead(self.scan, nxt))
             self.n_items = self.cur.records_pending()
             # (a batch that outgrows the slots sized from the one before is completed by a second all_to_all inside run():
             # xch.slot_overflows counts those; nothing is scanned twice)
@@ -557,6 +576,8 @@ def run_m(args, rank, world, local_rank):
             t0 = time.perf_counter()
             for _ in range(steps):
                 out = self.step()
+            if self.ahead is not None:                 # the scan the last step started belongs to the timed region: steps scans, steps exchanges
+                self.ahead[1].join()
             torch.cuda.synchronize()
             dist.barrier()
             elapsed = time.perf_counter() - t0
@@ -798,7 +819,6 @@ def main():
         h.push_device(n, n_words, ptrs, base_read_index=rank * n)
 
     def step():
-        import threading
         if overlap:
             if scanned[0] is None:                # the first step scans its own batch
                 scan(ex)
@@ -807,9 +827,7 @@ def main():
                 cur, th = scanned[0]
                 th.join()
             nxt = ex2 if cur is ex else ex
-            th = threading.Thread(target=scan, args=(nxt,))
-            th.start()
-            scanned[0] = (nxt, th)
+            scanned[0] = (nxt, LookAhead(scan, nxt))
         else:
             cur = ex
             scan(cur)
@@ -863,6 +881,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         table = step()
+    if scanned[0] is not None:           # the scan the last step started belongs to the timed region: steps scans, steps exchanges
+        scanned[0][1].join()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()

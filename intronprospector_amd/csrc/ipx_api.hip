@@ -1703,6 +1703,9 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     // (On every way out -- the early error returns included -- the stream is waited for before the caller's buffers are
     // let go: copies of the file's bytes and of the caller's block tables may still be under way, and the caller frees both
     // right after a failure: advisor, round 3.)
+    // (`order` is the source of an asynchronous copy from pageable memory further down: it is declared BEFORE `reg`, whose
+    // destructor waits for the stream, so that on every way out it outlives that wait -- advisor, round 4)
+    std::vector<uint32_t> order;
     struct Registered {
         hipStream_t s;
         void *p = nullptr;
@@ -1730,7 +1733,7 @@ int ipx_decode_bgzf(ipx_handle *h, const ipx_bgzf_file *f, ipx_batch *out) {
     if (f->n_tid_map) HIPCHK(hipMemcpyAsync(tb + t_map, f->tid_map, 4ull * f->n_tid_map, hipMemcpyHostToDevice, s));
     // the blocks longest first (by their compressed size): the lanes of a wave then take blocks of about one length and
     // the waves that start last are the short ones
-    std::vector<uint32_t> order(nb);
+    order.resize(nb);
     for (uint64_t b = 0; b < nb; ++b) order[b] = (uint32_t)b;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return f->payload_end[x] - f->payload_begin[x] > f->payload_end[y] - f->payload_begin[y];

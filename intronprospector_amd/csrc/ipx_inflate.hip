@@ -546,16 +546,32 @@ static void launch_inflate(hipStream_t s, const uint8_t *comp, const uint64_t *i
     // Lanes per wave: as few as still let EVERY wave be resident at once (three per SIMD by the kernel's registers).  A wave's turn lasts as long as its slowest lane's, so fewer lanes per wave wait less for each other and
     // more waves overlap their trips to memory -- until the waves no longer fit the chip and run in rounds (measured on
     // 36 316 blocks: 64 lanes 101 ms, 32: 91, 16: 81, 12: 74 = 3027 waves on 3072 places; 8: a second round).
-    static const uint32_t places = [] {
+    // (the kernel's dynamic LDS is lpw * 512 bytes: the occupancy is asked for with the LDS of the lpw in question -- 32 KB a
+    // wave at 64 lanes is five waves a CU, not the twelve that 8 KB allow -- advisor, round 4)
+    static const uint32_t n_cus = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate, 64, 16 * 512) != hipSuccess || per_cu <= 0) per_cu = 12;
-        (void)hipGetLastError();
-        return (uint32_t)cus * (uint32_t)per_cu;
+        return (uint32_t)cus;
     }();
+    auto places_at = [&](uint32_t l) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate, 64, (size_t)l * 512) != hipSuccess || per_cu <= 0) per_cu = 4;
+        (void)hipGetLastError();
+        return n_cus * (uint32_t)per_cu;
+    };
     const char *e = getenv("IPX_INFLATE_LPW");                            // (experiments)
-    uint32_t lpw = e ? (uint32_t)atoi(e) : (uint32_t)ipx_div_up(n_blocks, places - places / 64);
+    uint32_t lpw = 64;
+    if (e) {
+        lpw = (uint32_t)atoi(e);
+    } else {
+        // the fewest lanes per wave whose waves all fit the chip at once (tried at the sizes that matter: the answer is
+        // cached per size by the runtime's occupancy query being cheap, a few microseconds each)
+        static const uint32_t cand[] = {8, 12, 16, 24, 32, 48, 64};
+        for (uint32_t l : cand) {
+            const uint32_t pl = places_at(l);
+            if (ipx_div_up(n_blocks, l) <= pl - pl / 64) { lpw = l; break; }
+        }
+    }
     if (lpw < 1) lpw = 1;
     if (lpw > 64) lpw = 64;
     const dim3 grid((uint32_t)ipx_div_up(n_blocks, lpw));

@@ -653,8 +653,10 @@ __device__ __forceinline__ T load_arg(const __attribute__((address_space(4))) T 
     __builtin_memcpy(&v, src, sizeof(T));
     return v;
 }
-// k_scan_long3's argument block (see ShortArgs at k_scan_short for why): what only the staging of new alignments, the
-// packing of finished junctions and the pool's copy-out need is read from here at those points.
+// k_scan_long3's ONE parameter (the struct is the signature: the kernarg segment is this struct, nothing mirrors
+// anything).  The kernel holds more uniform values than a wave has scalar registers; what only the staging of new
+// alignments, the packing of finished junctions and the pool's copy-out need is read from the kernarg segment at those
+// points (fresh_long3_args(): the pointer is made opaque so that the scalar loads stay where they are written).
 struct Long3Args {
     ScanParams p;
     uint64_t n, n_words, base_read_index;
@@ -669,8 +671,6 @@ struct Long3Args {
     uint64_t capacity;
     Counters *counters;
 };
-static_assert(offsetof(Long3Args, reads_per_wave) == sizeof(ScanParams) + 24 && offsetof(Long3Args, a_tid) == sizeof(ScanParams) + 32 &&
-              offsetof(Long3Args, counters) == sizeof(ScanParams) + 152, "Long3Args must mirror k_scan_long3's parameter list");
 typedef const __attribute__((address_space(4))) Long3Args *Long3ArgsPtr;
 __device__ __forceinline__ Long3ArgsPtr fresh_long3_args() {
     Long3ArgsPtr k = (Long3ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -678,21 +678,11 @@ __device__ __forceinline__ Long3ArgsPtr fresh_long3_args() {
     return k;
 }
 
-__global__ __launch_bounds__(256, 3) void k_scan_long3(ScanParams p, uint64_t n, uint64_t n_words, uint64_t base_read_index,
-                                                   uint32_t reads_per_wave,
-                                                   const int32_t *__restrict__ a_tid,
-                                                   const int32_t *__restrict__ a_pos,
-                                                   const uint16_t *__restrict__ a_flag,
-                                                   const uint8_t *__restrict__ a_xs,
-                                                   const uint8_t *__restrict__ a_nh,
-                                                   const uint32_t *__restrict__ a_off,
-                                                   const uint32_t *__restrict__ a_nc,
-                                                   const uint32_t *__restrict__ cigar,
-                                                   const uint32_t *__restrict__ tail,
-                                                   const uint32_t *__restrict__ rank_of_tid,
-                                                   uint4 *__restrict__ items, uint4 *__restrict__ pays,
-                                                   uint32_t *__restrict__ cnts, uint8_t *__restrict__ digs,
-                                                   uint64_t capacity, Counters *counters) {
+__global__ __launch_bounds__(256, 3) void k_scan_long3(const Long3Args args) {
+    const ScanParams &p = args.p;
+    const uint64_t n = args.n, n_words = args.n_words;
+    const uint32_t reads_per_wave = args.reads_per_wave;
+    const uint32_t *const __restrict__ cigar = args.cigar, *const __restrict__ tail = args.tail;
     static_assert(LONG3_FAST + 2 <= LONG3_RINGW / 4, "a piece asked for at the top of a turn must be there before the lane needs it");
     __shared__ uint4 pool_item[4][LONG3_POOL], pool_pay[4][LONG3_POOL];
     __shared__ LongStage stage_s[4];
@@ -1485,10 +1475,11 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
         // (k_scan_long2: chunks of four plain ops on a fast path, lanes that met anything else waited for 40 others;
         // exact, 6.5 ms against 5.1 at 2 M alignments) -- DESIGN.md section 4 has the measurement, the history has the code
         // (IPX_LONG_PAD, the round-2 occupancy experiment's extra LDS per block, retired in round 4: NOTEBOOK.md)
-        if (v3)
-            hipLaunchKernelGGL(k_scan_long3, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
-                               b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,
-                               b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
+        if (v3) {
+            const Long3Args la{p, b.n_alignments, b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs,
+                               b.nh, b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters};
+            hipLaunchKernelGGL(k_scan_long3, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, la);
+        }
         else
             hipLaunchKernelGGL(k_scan_long, dim3((uint32_t)ipx_div_up(waves, 4)), dim3(256), 0, s, p, b.n_alignments,
                                b.n_cigar_words, b.base_read_index, (uint32_t)per_wave, b.tid, b.pos, b.flag, b.xs, b.nh,

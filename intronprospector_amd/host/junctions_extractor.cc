@@ -12,6 +12,9 @@
 #include <map>
 #include <cctype>
 #include <stdexcept>
+#include <exception>
+#include <system_error>
+#include <thread>
 
 namespace ipxhost {
 
@@ -780,13 +783,26 @@ void JunctionsExtractor::finalize_table() {
         if (want <= 1) {
             fill_rows(0, t.n_junctions);
         } else {
+            // A worker's exception (std::bad_alloc from a row's strings) is carried back and thrown here, after every
+            // thread that started has been joined; a thread that cannot be started has its range filled on this one.
             std::vector<std::thread> workers;
+            std::vector<std::exception_ptr> failed(want);
             const uint64_t step = (t.n_junctions + want - 1) / want;
             for (unsigned k = 0; k < want; ++k) {
                 const uint64_t lo = std::min<uint64_t>(t.n_junctions, (uint64_t)k * step), hi = std::min<uint64_t>(t.n_junctions, lo + step);
-                if (lo < hi) workers.emplace_back(fill_rows, lo, hi);
+                if (lo >= hi) continue;
+                auto guarded = [&fill_rows, &failed, k, lo, hi]() {
+                    try { fill_rows(lo, hi); } catch (...) { failed[k] = std::current_exception(); }
+                };
+                try {
+                    workers.emplace_back(guarded);
+                } catch (const std::system_error &) {
+                    guarded();
+                }
             }
             for (std::thread &w : workers) w.join();
+            for (const std::exception_ptr &e : failed)
+                if (e) std::rethrow_exception(e);
         }
     }
     // missing-sequence warnings, once per chromosome, in the order the reference meets them

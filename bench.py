@@ -486,6 +486,126 @@ def run_m1(args, local_rank):
                              "sample": "the oracle over the same 125 M alignments, one pass, %.1f s" % t_cpu}}
 
 
+def run_group(args):
+    """--multi group: BASELINE's config 5 through the PRODUCT's multi-GPU object, ipx_group (include/ipx.h, csrc/ipx_group.hip;
+    what `intronProspector --devices=0-7` runs): ONE process, N members, member m on GPU m (or, on a box with fewer GPUs,
+    several members sharing GPU 0 -- a rehearsal, and the line says so).  Member m holds rank m's contiguous 12.5 chunks of
+    the M stream in ITS device's memory; a step = ipx_group_clear, every member's pieces pushed from device memory
+    (ipx_group_push_member), ipx_group_finalize (scan per member, junction records to their key-range owners over RCCL --
+    or device copies between members of one GPU --, every owner's sort + reduce, ONE table).  The same checks as the
+    torch.distributed path: conservation, sjN a permutation, rows in key order, and -- on a down-scaled stream -- the
+    whole table against the oracle's."""
+    import torch
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth, config5
+    from tests import helpers
+    from tests.oracle_binding import Oracle
+    members = args.gpus
+    n_dev = torch.cuda.device_count()
+    devices = list(range(members)) if n_dev >= members else [0] * members
+    chunk = args.chunk or 10_000_000
+
+    class Stream:
+        def __init__(self, chunk_alignments, keep_host):
+            self.ups, self.sizes, self.host, self.bases, self.names = [], [], [], [], None
+            t0 = time.perf_counter()
+            for m in range(members):
+                dev = torch.device("cuda", devices[m])
+                ups, sizes = [], []
+                for c, lo, hi in config5.rank_pieces(m, chunk_alignments):
+                    b, self.names = config5.make_piece(c, lo, hi, chunk_alignments)
+                    ups.append(upload(b, dev))
+                    sizes.append((len(b["tid"]), len(b["cigar"])))
+                    if keep_host:
+                        self.host.append(b)
+                self.ups.append(ups)
+                self.sizes.append(sizes)
+                self.bases.append(config5.rank_base(m, chunk_alignments))
+            self.n = sum(a for sz in self.sizes for a, _ in sz)
+            self.n_words = sum(w for sz in self.sizes for _, w in sz)
+            self.generate_s = time.perf_counter() - t0
+            self.grp = ipa.JunctionsExtractorGroup(devices, targets=self.names)
+
+        def step(self):
+            self.grp.clear()
+            for m in range(members):
+                base = self.bases[m]
+                for (na, nw), (_, ptrs) in zip(self.sizes[m], self.ups[m]):
+                    self.grp.push_member_device(m, na, nw, ptrs, base)
+                    base += na
+            return self.grp.get_junctions()
+
+    def checks_of(tab):
+        J = len(tab["intron_start"])
+        key = np.stack([tab["target"].astype(np.int64), tab["intron_start"].astype(np.int64), tab["intron_end"].astype(np.int64)], 1)
+        asc = True
+        if J > 1:
+            a, b = key[:-1], key[1:]
+            asc = bool(((a[:, 0] < b[:, 0]) | ((a[:, 0] == b[:, 0]) & ((a[:, 1] < b[:, 1]) | ((a[:, 1] == b[:, 1]) & (a[:, 2] < b[:, 2]))))).all())
+        counted = int(tab["counts"].astype(np.uint64).sum())
+        return {"junctions": J, "reads_counted": counted, "records_made": int(tab["n_records"]),
+                "conservation": counted == int(tab["n_records"]),
+                "ijunc_is_a_permutation": bool(np.array_equal(np.sort(tab["ijunc"].astype(np.int64)), np.arange(J))),
+                "rows_in_key_order": asc}
+
+    main_s = Stream(chunk, keep_host=False)
+    for _ in range(max(args.warmup, 2)):
+        tab = main_s.step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tab = main_s.step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    if "error" in tab:
+        raise tab["error"]
+    checks = checks_of(tab)
+    uses_rccl = main_s.grp.uses_rccl()
+    n, nw, gen_s = main_s.n, main_s.n_words, main_s.generate_s
+    main_s.grp.close()
+    del main_s
+
+    # parity: the same code over a down-scaled stream, the whole table against the oracle's
+    small_chunk = int(min(400_000, 20_000_000 // (12.5 * members))) // 2 * 2
+    sm = Stream(small_chunk, keep_host=True)
+    for _ in range(2):
+        tab_s = sm.step()
+    t0 = time.perf_counter()
+    ora = Oracle(targets=sm.names)
+    for b in sm.host:
+        ora.process(b)
+    ref = ora.table()
+    ora.close()
+    try:
+        helpers.compare_tables(tab_s, ref)
+        parity = {"equals_oracle": True}
+    except AssertionError as e:
+        parity = {"equals_oracle": False, "error": str(e)[:300]}
+    parity.update({"alignments": sm.n, "junctions": int(len(ref["intron_start"])), "chunk_alignments": small_chunk,
+                   "oracle_s": time.perf_counter() - t0, "checks": checks_of(tab_s)})
+    sm.grp.close()
+    ms = elapsed / args.steps * 1e3
+    r = checks["records_made"]
+    b_alg = 20 + 4 * nw / n + 64 * r / n
+    per_gpu = len(set(devices))
+    return {"metric": "alignments/sec junction extraction", "value": n * args.steps / elapsed, "unit": "alignments/s",
+            "n_gpus": per_gpu, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+            "config": {"workload": "M through ipx_group: %d member(s) x 12.5 chunks of %d alignments (chunk i from seed %d + i) = %d short "
+                                   "reads, one process, devices %s%s, %d junctions" % (
+                                       members, chunk, synth.SEED_M0, n, devices,
+                                       "" if per_gpu == members else " (REHEARSAL: members share a GPU)", checks["junctions"]),
+                       "multi": "group", "members": members, "devices": devices, "uses_rccl": uses_rccl,
+                       "alignments": n, "cigar_words": nw, "generate_s": gen_s, "checks": checks, "parity": parity,
+                       "input": "SoA chunks resident in each member's HBM before the timed region; the table comes back to host memory "
+                                "inside the timed step (ipx_group_finalize)"},
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "achieved": b_alg * n / per_gpu / (ms * 1e-3) / 1e9, "frac": b_alg * n / per_gpu / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "note": "per GPU: algorithmic bytes (20 + 4c + 64j per alignment) of the GPU's members / the step"}}
+
+
 def run_m(args, rank, world, local_rank):
     """N > 1 (and --workload M): BASELINE.json's config 5.  Every rank holds its contiguous 12.5 chunks of the M stream
     (intronprospector_amd/config5.py: 125 M alignments at full size) resident in HBM; a step = ipx_clear + its pushes
@@ -709,8 +829,11 @@ def main():
     ap.add_argument("--shuffle", action="store_true",
                     help="alignments in random order instead of coordinate order (the reference's whole-file mode "
                          "accepts unsorted input): what the step costs without any locality")
-    ap.add_argument("--multi", default="exchange", choices=["exchange", "tables"],
-                    help="N>1: exchange junction records by key range (default) or merge shard tables")
+    ap.add_argument("--multi", default="exchange", choices=["exchange", "group"],
+                    help="N>1.  exchange (default; what the driver's torch.distributed launch measures): one process per GPU, this "
+                         "package's harness over libipx's slot exchange entry points and torch.distributed collectives.  group: ONE "
+                         "process drives --gpus members through ipx_group (the product's --devices path; run WITHOUT "
+                         "torch.distributed.run; members share GPU 0 on a box with fewer GPUs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a one-GPU box (tables merged on the CPU)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -727,6 +850,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.multi == "group":
+        if world != 1:
+            raise SystemExit("--multi group is one process: run it without torch.distributed.run")
+        import torch            # before the package: libipx.so must bind to the HIP runtime torch brings along
+        out = run_group(args)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+        return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
@@ -789,16 +921,15 @@ def main():
     ex = ipa.JunctionsExtractor(targets=names, device=local_rank, **params)
     ex.reserve(0, 0, n_words // 2 + 1024)
 
-    merger = None
+    # (the table-merge formulation of the exchange step -- all_gather of key lists, all_reduce of dense tables: SURVEY 8e
+    # steps 2-4 -- was a bench option through round 4: 440 ms against the record exchange's 57 ms on two ranks.  Retired
+    # from the bench in round 5; distributed.merge_shard_tables stays as the tests' second formulation)
     exchanger = None
     if multi:
         from intronprospector_amd import distributed
         comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
-        if args.multi == "tables":
-            merger = distributed.TableMerger(comm_dev)
-        else:
-            exchanger = distributed.RecordExchanger(dev, comm_device=comm_dev)
-            exchanger.strict = False              # the ranks' finalize errors are looked at once, after the timed steps
+        exchanger = distributed.RecordExchanger(dev, comm_device=comm_dev)
+        exchanger.strict = False              # the ranks' finalize errors are looked at once, after the timed steps
 
     n_records = [0]
     n_merged = [0]
@@ -837,12 +968,6 @@ def main():
             table, ijunc = exchanger.run(cur, n)
             n_records[0] = table.n_records
             n_merged[0] = int(table.n_junctions)          # this rank's key range; summed after the timed loop
-            return table
-        if merger is not None:
-            # partial tables of this rank's shard -> RCCL merge of the junction tables
-            merged, table = merger.merge(ex, rank * n)
-            n_records[0] = table.n_records
-            n_merged[0] = int(merged["target"].shape[0])
             return table
         rc, table = ex.finalize_raw(L.IPX_MEM_DEVICE)
         if rc:

@@ -419,31 +419,57 @@ int ipx_group_finalize(ipx_group *g, ipx_table *out) {
     g->anchor_end.resize(J); g->ijunc.resize(J); g->strand.resize(J); g->motif.resize(J);
     g->read_counts.resize(3 * J); g->creator_order.resize(J); g->hist_begin.resize(J + 1);
     g->hist_value.resize(B); g->hist_count.resize(B);
-    uint64_t j0 = 0, b0 = 0;
-    for (const ipx_table &t : tabs) {
-        const uint64_t n = t.n_junctions;
-        if (n) {
-            memcpy(&g->target[j0], t.target, n * 4); memcpy(&g->intron_start[j0], t.intron_start, n * 4);
-            memcpy(&g->intron_end[j0], t.intron_end, n * 4); memcpy(&g->anchor_start[j0], t.anchor_start, n * 4);
-            memcpy(&g->anchor_end[j0], t.anchor_end, n * 4); memcpy(&g->strand[j0], t.strand, n);
-            memcpy(&g->motif[j0], t.motif, n * 2); memcpy(&g->read_counts[3 * j0], t.read_counts, 3 * n * 8);
-            memcpy(&g->creator_order[j0], t.creator_order, n * 8);
-            for (uint64_t k = 0; k < n; ++k) g->hist_begin[j0 + k] = t.hist_begin[k] + b0;
-        }
-        if (t.n_hist) {
-            memcpy(&g->hist_value[b0], t.hist_value, t.n_hist * 2);
-            memcpy(&g->hist_count[b0], t.hist_count, t.n_hist * 4);
-        }
-        j0 += n;
-        b0 += t.n_hist;
+    // (every member's rows are copied by a thread of its own: at millions of junctions the copies are the step)
+    std::vector<uint64_t> j_at(P + 1, 0), b_at(P + 1, 0);
+    for (size_t i = 0; i < P; ++i) { j_at[i + 1] = j_at[i] + tabs[i].n_junctions; b_at[i + 1] = b_at[i] + tabs[i].n_hist; }
+    {
+        std::vector<int> crc;
+        for_members(g, crc, [&](size_t i) -> int {
+            const ipx_table &t = tabs[i];
+            const uint64_t n = t.n_junctions, j0 = j_at[i], b0 = b_at[i];
+            if (n) {
+                memcpy(&g->target[j0], t.target, n * 4); memcpy(&g->intron_start[j0], t.intron_start, n * 4);
+                memcpy(&g->intron_end[j0], t.intron_end, n * 4); memcpy(&g->anchor_start[j0], t.anchor_start, n * 4);
+                memcpy(&g->anchor_end[j0], t.anchor_end, n * 4); memcpy(&g->strand[j0], t.strand, n);
+                memcpy(&g->motif[j0], t.motif, n * 2); memcpy(&g->read_counts[3 * j0], t.read_counts, 3 * n * 8);
+                memcpy(&g->creator_order[j0], t.creator_order, n * 8);
+                for (uint64_t k = 0; k < n; ++k) g->hist_begin[j0 + k] = t.hist_begin[k] + b0;
+            }
+            if (t.n_hist) {
+                memcpy(&g->hist_value[b0], t.hist_value, t.n_hist * 2);
+                memcpy(&g->hist_count[b0], t.hist_count, t.n_hist * 4);
+            }
+            return IPX_OK;
+        });
     }
     g->hist_begin[J] = B;
-    // ijunc = rank of the creation order (junctions_extractor.cc:459-460), over the whole run
+    // ijunc = rank of the creation order (junctions_extractor.cc:459-460), over the whole run.  Every member's table
+    // carries the ranks WITHIN the member (its own ijunc): inverted, they are the member's rows in creation order, and
+    // the run's order is a merge of those P sorted lists -- O(J P) in streams (round 4 sorted J indices through their
+    // 64-bit orders on one thread: 0.2 s of a 0.22 s step at 2.7 M junctions)
     if (P > 1) {
-        std::vector<uint32_t> idx(J);
-        std::iota(idx.begin(), idx.end(), 0u);
-        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return g->creator_order[a] < g->creator_order[b]; });
-        for (uint64_t k = 0; k < J; ++k) g->ijunc[idx[k]] = (uint32_t)k;
+        std::vector<std::vector<uint32_t>> by_order(P);
+        {
+            std::vector<int> crc;
+            for_members(g, crc, [&](size_t i) -> int {
+                const uint64_t n = tabs[i].n_junctions;
+                by_order[i].resize(n);
+                for (uint64_t k = 0; k < n; ++k) by_order[i][tabs[i].ijunc[k]] = (uint32_t)k;
+                return IPX_OK;
+            });
+        }
+        std::vector<uint64_t> head(P, 0);
+        for (uint64_t r = 0; r < J; ++r) {
+            size_t best = P;
+            uint64_t best_o = 0;
+            for (size_t i = 0; i < P; ++i) {
+                if (head[i] == by_order[i].size()) continue;
+                const uint64_t o = g->creator_order[j_at[i] + by_order[i][head[i]]];
+                if (best == P || o < best_o) { best = i; best_o = o; }
+            }
+            g->ijunc[j_at[best] + by_order[best][head[best]]] = (uint32_t)r;
+            ++head[best];
+        }
     } else if (J) {
         memcpy(g->ijunc.data(), tabs[0].ijunc, J * 4);
     }

@@ -157,3 +157,23 @@ def test_cli_devices_option(oracle_cli):
         assert outs[0] == outs[1] and len(outs[0][0]) > 500
         exp = open(os.path.join(ROOT, "tests", "golden", "expected", "testBasic1.introns.tsv")).read()
         assert outs[1][0] == exp
+
+
+def test_bench_multi_group_config5_downscaled():
+    """bench.py --multi group: config 5's shares (member m = rank m's contiguous 12.5 chunks) through ipx_group with two
+    members on the test GPU, down-scaled; the line carries conservation, global sjN, key order and the oracle parity
+    record -- what the driver-comparable line of the product's own multi-GPU path must hold at any size"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--multi", "group", "--gpus", "2", "--chunk", "200000",
+                        "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    cfg = line["config"]
+    assert cfg["multi"] == "group" and cfg["members"] == 2
+    for c in (cfg["checks"], cfg["parity"]["checks"]):
+        assert c["conservation"] and c["ijunc_is_a_permutation"] and c["rows_in_key_order"], c
+    assert cfg["parity"]["equals_oracle"], cfg["parity"]
+    assert cfg["alignments"] == 2 * 25 * 100_000 and line["value"] > 0

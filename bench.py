@@ -328,6 +328,10 @@ def roofline_block(kind, n, n_words, r, m, ms_per_step, dominant, timed, stats, 
         out.update({
             "kernel": dominant, "kernel_launches_per_step": launches / steps, "kernel_avg_ms": avg_ms,
             "kernel_bytes_per_launch": kb, "kernel_achieved": kb / (avg_ms * 1e-3) / 1e9,
+            # what the kernel class must move per launch (the same figure, under the name the review asked for) and what the
+            # PMC counters saw it move (profiles/traffic.json; upper end of the range for mixed access patterns)
+            "kernel_necessary_bytes": kb,
+            "kernel_traffic": (tr.get(dominant) / (launches / steps)) if tr.get(dominant) else None,
             "kernel_frac": kb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # PMC bytes of this kernel class per STEP (all its launches; profiles/traffic.json)
             "kernel_traffic_step_bytes": tr.get(dominant),

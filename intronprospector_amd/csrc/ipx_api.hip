@@ -132,7 +132,6 @@ struct ipx_handle {
     // records
     DevBuf items_a, items_b, pays, cnts, dig_a, dig_b;
     bool opt_combine = true;       // IPX_OPT_COMBINE: the short-read scan may merge equal-key records of a tile
-    bool comb_probe = false;       // the last batch found too little to merge: only every sixteenth tile still tries
     uint32_t bsort_skip = 0;       // finalizes that go straight to the radix passes after the bucket sort overflowed
     unsigned long long spl_host[64] = {};      // the splitters the device copy holds (ipx_records_partition_slots)
     bool spl_valid = false;
@@ -736,10 +735,6 @@ static int push_launch(ipx_handle *h) {
     const bool combine_env = !(combine_e && combine_e[0] == '0');
     const bool filter_active = h->have_genome && h->params.sj_filter == IPX_SJ_CANON;
     sp.combine = (h->opt_combine && combine_env) ? (filter_active ? 2u : 1u) : 0u;
-    {
-        const char *adapt_e = getenv("IPX_COMBINE_ADAPT");        // "0": never probe (tests compare both)
-        sp.combine_mask = (sp.combine && h->comb_probe && !(adapt_e && adapt_e[0] == '0')) ? 15u : 0u;
-    }
     sp.skip_missing = h->params.skip_missing_targets;
     sp.rank_is_tid = h->params.scope == IPX_SCOPE_TARGET ? 1u : 0u;
     if (filter_active) sp.genome = genome_dev(h);
@@ -753,7 +748,7 @@ static int push_launch(ipx_handle *h) {
     pp.use_ops = !h->force_lane_scan;
     pp.use_stripes = true;
     pp.attempt = 0;
-    // list of the alignments k_scan_short hands on to k_scan_rest (at most all of them)
+    // list of the alignments the short-read scan hands on to k_scan_rest (at most all of them)
     if ((rc = ensure(h, h->defer, ipx_scan_list_words(n) * sizeof(uint32_t)))) return rc;
     ProfScope prof_scope(&h->prof);
     if ((rc = launch_scan_attempt(h))) return rc;
@@ -849,19 +844,10 @@ static int push_complete(ipx_handle *h) {
             return fail(h, IPX_EINVAL, "ipx_push_bam: malformed BAM record%s (alignment %ld of the batch)", "", (long)bad - 1);
         }
         if (getenv("IPX_DEBUG_PLAN"))
-            fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away%s, %u alignments left to the second stage\n",
-                    (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged,
-                    pp.sp.combine_mask ? " (probing: one tile in sixteen combines)" : "", n_defer);
+            fprintf(stderr, "ipx: scan of %llu alignments: %llu records, %llu merged away, %u alignments left to the second stage\n",
+                    (unsigned long long)pp.n, (unsigned long long)(c->n_records - h->n_records), (unsigned long long)merged, n_defer);
         // (the second stage ran behind the first on the device, see ipx_launch_scan; the count sizes the next one's grid)
         h->rest_hint = n_defer;
-        // the combiner adapts: little merged -> the next batches only probe; the probe tiles merge again -> back
-        if (!pp.use_ops && pp.sp.combine && c->n_records > h->n_records) {
-            const double raw = (double)(c->n_records - h->n_records) + (double)merged;
-            if (raw >= 65536.0) {
-                if (pp.sp.combine_mask == 0) { if ((double)merged < 0.10 * raw) h->comb_probe = true; }
-                else if (16.0 * (double)merged >= 0.25 * raw) h->comb_probe = false;
-            }
-        }
         if (!layout_bad && !stripes_bad && c->n_records <= h->rec_cap) {
             for (int k = 0; k < 3; ++k) { h->key_or[k] = c->key_or[k]; h->key_and[k] = c->key_and[k]; }
             h->err_word_host = c->err_word;

@@ -31,11 +31,11 @@
 //
 // Next to the two halves every record has a 4-byte count word (cnts[], indexed like pays[]):
 //   c0 | c1 << 10 | c2 << 20 = how many reads of category 0/1/2 the record stands for.
-// A record straight from a CIGAR has one bit set (none when cat == 3).  The short-read scan COMBINES
-// the records of a tile that share the whole 96-bit key (same junction, same read offset) before they
-// leave the LDS pool -- a coordinate-sorted pile-up on a hot junction hands the sort one record per
-// (junction, offset) and tile instead of hundreds: order64 = the smallest of the group (with that
-// record's strand), anchors = min / max, counts = sums.  See k_scan_short.
+// A record straight from a CIGAR has one bit set (none when cat == 3).  The short-read scan FOLDS
+// records that share the whole 96-bit key (same junction, same read offset) before they leave the
+// kernel -- a coordinate-sorted pile-up on a hot junction hands the sort one record per (junction,
+// offset) and wave tile instead of hundreds: order64 = the smallest of the group (with that record's
+// strand), anchors = min / max, counts = sums.  See ipx_scan_short.inc.
 #define IPX_CNT_BITS 10
 #define IPX_CNT_MASK 0x3ffu
 #define IPX_CNT_ONE(cat) ((cat) < 3u ? (1u << (IPX_CNT_BITS * (cat))) : 0u)
@@ -97,17 +97,12 @@ struct ScanParams {
     // closes the gaps the stripes leave, so everybody else sees base + n dense records.
     uint64_t base;
     uint32_t n_stripes;
-    // 1: k_scan_short combines equal-key records of a tile (off when the caller wants every record:
-    // ipx_records_export, or when a record may fail the junction filter -- see ipx_push_batch)
-    // 2: the same under an active junction filter (genome + "canon"): a record is combined only if IT would
-    // pass the filter against its junction's motif (looked up here, per record); records that fail stay single,
-    // because the reduce drops those that precede the junction's creator one by one
+    // 1: the short-read scan folds records of equal key (ipx_scan_short.inc; off when the caller wants every record:
+    // ipx_records_export)
+    // 2: the same under an active junction filter (genome + "canon"): a record is folded only if IT would pass the
+    // filter against its junction's motif (looked up in the scan, once per run of equal keys); records that fail stay
+    // single, because the reduce drops those that precede the junction's creator one by one
     uint32_t combine;
-    // 0: every tile combines.  15: only tiles whose number is a multiple of 16 do -- a PROBE.  Input in random order
-    // finds next to nothing to merge (S shuffled: 5 %) and paid a tenth of its step for the attempt; ipx_push_batch
-    // switches a handle to probing when a batch merged less than a tenth of its records and back when the probe
-    // tiles merge a quarter of theirs (the reference reads unsorted input too: intronProspector.cc:375-387).
-    uint32_t combine_mask;
     int32_t skip_missing;
     // the key rank of a tid is the tid itself (IPX_SCOPE_TARGET): the scan then skips the dependent load of
     // rank_of_tid[tid], one round trip per tile of short reads

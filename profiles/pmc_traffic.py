@@ -21,7 +21,7 @@ import re
 import sys
 
 CLASS = [
-    (r"k_scan_short|k_scan_long|k_scan_rest|k_scan_ops|k_close_|k_cigar_tail", "k_scan"),
+    (r"k_scan_short|k_scan_long|k_scan_rest|k_scan_ops|k_close|k_cigar_tail", "k_scan"),
     (r"k_scatter", "k_scatter"), (r"k_hist", "k_hist"), (r"k_binscan", "k_binscan"),
     (r"k_bs_leaf", "k_bs_leaf"), (r"k_bs_assign", "k_bs_assign"), (r"k_bs_sample|k_bs_sort2", "k_bs_sample"), (r"k_bs_bounds", "k_bs_bounds"),
     (r"k_reduce<1>", "k_reduce_a"), (r"k_reduce", "k_reduce"),

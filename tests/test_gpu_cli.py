@@ -420,3 +420,46 @@ def test_cli_unknown_cigar_op_error(cli, tmp_path):
     r = subprocess.run([cli, "--intron-calls=/dev/stdout", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1
     assert r.stderr.decode() == "Error: Unknown cigar operation 'P'\nUse --help to get usage\n"
+
+
+def test_cli_confidence_at_scale_against_the_oracle(cli, oracle_cli, tmp_path):
+    """`confidence` at scale.  1.2 M coordinate-sorted alignments over 30 000 junction sites
+    (hundreds of reads and dozens of distinct read offsets a junction: entropies all over the range) as a BGZF BAM
+    through the product's command line -- inflated, decoded, scanned, reduced on the device, confidence from the
+    device's histogram on the host -- against the oracle's command line on the same alignments as SAM text: the calls
+    file (junctions.cc:54-70 behind `%.3g`, the default 1.0 threshold AND threshold 0), byte for byte."""
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(1_200_000, seed=4242, n_targets=4, target_len=30_000_000, n_sites=30_000)
+    ops = "MIDNSHP=XB"
+    sam = str(tmp_path / "big.sam")
+    cig, off, nc = batch["cigar"], batch["cigar_off"], batch["n_cigar"]
+    lens, codes = (cig >> 4).tolist(), (cig & 15).tolist()
+    with open(sam, "w") as f:
+        f.write("@HD\tVN:1.6\tSO:coordinate\n")
+        for n in names:
+            f.write("@SQ\tSN:%s\tLN:30000000\n" % n)
+        tid, pos, flag, xs, nh = (batch[k].tolist() for k in ("tid", "pos", "flag", "xs", "nh"))
+        o, c = off.tolist(), nc.tolist()
+        for i in range(len(tid)):
+            cs = "".join("%d%s" % (lens[k], ops[codes[k]]) for k in range(o[i], o[i] + c[i]))
+            tags = []
+            if nh[i] == 1:
+                tags.append("NH:i:1")
+            elif nh[i] == 2:
+                tags.append("NH:i:3")
+            if xs[i]:
+                tags.append("XS:A:%s" % chr(xs[i]))
+            f.write("\t".join(["r%d" % i, str(flag[i]), names[tid[i]], str(pos[i] + 1), "60", cs, "*", "0", "0", "*", "*"] + tags) + "\n")
+    bam = str(tmp_path / "big.bam")
+    bamio.sam_to_bam(sam, bam, aligned=True)
+    for opts in (["--min-confidence-score=0.0"], []):
+        outs = []
+        for exe, inp, env in ((cli, bam, dict(os.environ, IPX_DEVICE_INFLATE="1")), (oracle_cli, sam, None)):
+            tsv = str(tmp_path / "big.tsv")
+            subprocess.run([exe] + opts + ["--intron-calls=" + tsv, inp], check=True, env=env)
+            with open(tsv, "rb") as g:
+                outs.append(g.read())
+        assert outs[0] == outs[1], opts
+        rows = outs[0].decode().splitlines()[1:]
+        conf = [float(r.split("\t")[9]) for r in rows]
+        assert len(rows) > 20_000 and max(conf) > 5.0 and len(set(conf)) > 200      # real entropies, not a table of zeros

@@ -1051,9 +1051,17 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(const Long3Args args) {
             const bool lr = (state & (ST_LEFT | ST_RIGHT)) != 0u;
             const uint32_t lim = lr ? lim1 : 0u;
             const uint32_t m_l = state == ST_LEFT ? ~0u : 0u;
+            // The words of all the plain steps are read up front, from cw on: a step that does not apply leaves cw where it
+            // is, and so do all the steps behind it (the same word fails the same way), so step k applies exactly if it
+            // finds cw == cw0 + k -- with the word read at the step, from an address that depends on the step before, a
+            // turn was six dependent trips to LDS (round 5)
+            const uint32_t cw0 = cw;
+            uint32_t wk[LONG3_FAST];
+#pragma unroll
+            for (uint32_t k = 0; k < LONG3_FAST; ++k) wk[k] = my_ring[(cw0 + k) & (LONG3_RINGW - 1u)][lane];
 #pragma unroll
             for (uint32_t k = 0; k < LONG3_FAST; ++k) {
-                const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
+                const uint32_t w = wk[k];
                 const uint32_t op = w & 0xfu, len = w >> 4;
                 const uint32_t code = (uint32_t)(PLAIN_CODES >> (op * 4u));
                 const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
@@ -1061,7 +1069,7 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(const Long3Args args) {
                 const uint32_t tpn = tp + (len & m_adv);
                 const uint32_t il = len & m_id;
                 const uint32_t ci = (cur_indel + il) & ~m_m;             // I/D :257-275 add up, M = X :232-255 start over
-                const bool ok = cw < lim && (code & 0xfu) != 0u && ci <= p.max_anchor_indel_size;
+                const bool ok = cw == cw0 + k && cw < lim && (code & 0xfu) != 0u && ci <= p.max_anchor_indel_size;
                 if (ok) {
                     tp = tpn;
                     ae = (tpn & m_m) | (ae & ~m_m);

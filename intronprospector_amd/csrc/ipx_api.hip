@@ -133,6 +133,10 @@ struct ipx_handle {
     DevBuf items_a, items_b, pays, cnts, dig_a, dig_b;
     bool opt_combine = true;       // IPX_OPT_COMBINE: the short-read scan may merge equal-key records of a tile
     uint32_t bsort_skip = 0;       // finalizes that go straight to the radix passes after the bucket sort overflowed
+    // the bit runs on which the creation orders of the last finalize's junctions differed (ipx_finalize ranks the NEXT
+    // table's through them before it knows that table's own: see "speculated" there)
+    RankBits rank_hint{};
+    bool rank_hint_ok = false;
     unsigned long long spl_host[64] = {};      // the splitters the device copy holds (ipx_records_partition_slots)
     bool spl_valid = false;
     void *spl_where = nullptr;
@@ -975,6 +979,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
     hipStream_t s = h->stream;
     uint32_t *small = (uint32_t *)h->pin_small;
     uint32_t J = 0, B = 0, n_valid = 0, n_hist = 0;
+    bool ranked_early = false;      // the table's ijunc was queued before the last read-back, which therefore was the completion
     ReduceBuffers rb{};
     unsigned long long err_word = IPX_ERRW_NONE;
 
@@ -1123,6 +1128,20 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         HIPCHK(ipx_launch_reduce(s, si, h->pays.as<uint4>(), cnts_or_null, h->key, rb, g, sj_filter,
                                  h->params.skip_missing_targets, h->d_tid_of_rank.as<uint32_t>(),
                                  h->counters.as<Counters>()));
+        // ijunc = rank of the creation order, through a bitmap over the bits on which the orders differ -- bits the host
+        // learns from the read-back below, a round trip during which the GPU idles (~10 us of a 0.56 ms step).  Without a
+        // genome nothing is dropped (n_valid == J), and a table's orders mostly differ on the bits the last table's did:
+        // the rank kernels are queued BEFORE the read-back with the last finalize's runs, and stand if the read-back shows
+        // that this table's varying bits lie inside them (bits that do not vary only widen the bitmap's index, the ranks
+        // are the same); otherwise they run again, as before.
+        const char *rank_env = getenv("IPX_RANK");                  // "sort": always the radix sort (tests)
+        const bool force_sort = rank_env && rank_env[0] == 's';
+        bool speculated = false;
+        if (!h->have_genome && h->rank_hint_ok && J && !force_sort) {
+            if ((rc = ensure(h, h->rank_bitmap, ipx_rank_bitmap_workspace_bytes(h->rank_hint.bits)))) return rc;
+            HIPCHK(ipx_launch_rank_by_bitmap(s, J, rb.rank_a, h->rank_hint, h->rank_bitmap.as<uint32_t>(), rb.out_ijunc));
+            speculated = true;
+        }
         if ((rc = read_back(h, small, rb.totals, 8, h->counters.p, sizeof(Counters) / 4))) return rc;
         h->prof.collect();
         ipx_prof_mark(s, IPXK_BEGIN);
@@ -1147,9 +1166,31 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
                 rbits.bits += w;
                 b += w;
             }
-            const char *rank_env = getenv("IPX_RANK");                  // "sort": always the radix sort (tests)
-            const bool force_sort = rank_env && rank_env[0] == 's';
-            if (by_bitmap && rbits.bits <= 28 && !force_sort) {
+            uint64_t hint_mask = 0;
+            for (uint32_t k = 0; k < h->rank_hint.n_runs; ++k)
+                hint_mask |= (h->rank_hint.width[k] >= 64 ? ~0ull : ((1ull << h->rank_hint.width[k]) - 1ull)) << h->rank_hint.lo[k];
+            const bool stands = speculated && n_valid == J && (rv & ~hint_mask) == 0;
+            if (by_bitmap && rbits.bits <= 28) {
+                // (the next table is ranked through the union of what was seen: a hint that only grows keeps standing)
+                RankBits u{};
+                const uint64_t um = h->rank_hint_ok ? (hint_mask | rv) : rv;
+                bool fits = true;
+                for (uint32_t b = 0; b < 64;) {
+                    if (!((um >> b) & 1u)) { ++b; continue; }
+                    uint32_t w = 0;
+                    while (b + w < 64 && ((um >> (b + w)) & 1u)) ++w;
+                    if (u.n_runs == 4) { fits = false; break; }
+                    u.lo[u.n_runs] = b; u.width[u.n_runs++] = w; u.bits += w;
+                    b += w;
+                }
+                if (fits && u.bits <= 28) { h->rank_hint = u; h->rank_hint_ok = true; }
+                else { h->rank_hint = rbits; h->rank_hint_ok = true; }
+            } else {
+                h->rank_hint_ok = false;
+            }
+            if (stands) {
+                ranked_early = true;
+            } else if (by_bitmap && rbits.bits <= 28 && !force_sort) {
                 if ((rc = ensure(h, h->rank_bitmap, ipx_rank_bitmap_workspace_bytes(rbits.bits)))) return rc;
                 HIPCHK(ipx_launch_rank_by_bitmap(s, n_valid, rb.rank_a, rbits, h->rank_bitmap.as<uint32_t>(), rb.out_ijunc));
             } else {
@@ -1183,7 +1224,7 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         t.motif = rb.out_motif; t.read_counts = rb.out_read_counts; t.creator_order = rb.out_creator_order;
         t.ijunc = rb.out_ijunc; t.hist_begin = rb.out_hist_begin; t.hist_value = rb.out_hist_value;
         t.hist_count = rb.out_hist_count;
-        if ((rc = read_back(h, small + 48, nullptr, 0))) return rc;      // completion only
+        if (!ranked_early && (rc = read_back(h, small + 48, nullptr, 0))) return rc;      // completion only
     } else {
         // pinned host copy, same section layout
         Arena ha;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define IPX_ABI_VERSION 4
+#define IPX_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -439,6 +439,19 @@ int ipx_group_clear(ipx_group *g);
 int ipx_group_last_error(const ipx_group *g, ipx_error *out);
 /* 1 if the group's exchange runs over RCCL, 0 if over peer copies (members sharing a device) */
 int ipx_group_uses_rccl(const ipx_group *g);
+
+/* Global sjN across key ranges (ABI 5).  The reference numbers junctions in the order it creates them
+ * (junctions_extractor.hh:129,202; junctions_extractor.cc:459-460); after a record exchange every rank (or group member)
+ * holds a key range, and a junction's number is the rank of its creation order among ALL ranges' junctions.
+ * ipx_table_sorted_orders writes the creation orders of `table` (a device table of this handle's last ipx_finalize) in
+ * ascending order to out[0 .. capacity) in device memory -- the table's own ijunc is that permutation -- and fills the rest
+ * with UINT64_MAX: lists of one agreed length can be all-gathered without exchanging lengths.
+ * ipx_table_global_ijunc takes n_lists such lists of `length` words each (device memory, `stride` words apart) and
+ * writes, for every junction of `table`, the number of smaller orders in all of them: its global sjN.  Both are queued on the handle's stream and
+ * do not wait.  (Rounds 2-4 did this in the Python harness with torch index, searchsorted and sum ops.) */
+int ipx_table_sorted_orders(ipx_handle *h, const ipx_table *table, uint64_t *out, uint64_t capacity);
+int ipx_table_global_ijunc(ipx_handle *h, const ipx_table *table, const uint64_t *lists, uint32_t n_lists,
+                           uint64_t stride, uint64_t length, uint32_t *out_ijunc);
 
 /* copy between any two of {host, device} on the handle's stream, then wait */
 int ipx_copy(ipx_handle *h, void *dst, const void *src, uint64_t bytes);

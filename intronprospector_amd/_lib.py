@@ -31,6 +31,7 @@ SYMBOLS = [
     "ipx_push_batch_async", "ipx_sync", "ipx_host_alloc", "ipx_host_free",
     "ipx_push_bam", "ipx_push_bam_async", "ipx_bgzf_inflate",
     "ipx_records_partition_slots", "ipx_records_adopt_slots", "ipx_records_partition_slots_spill", "ipx_records_adopt_more", "ipx_use_stream", "ipx_copy_async", "ipx_decode_bgzf",
+    "ipx_table_sorted_orders", "ipx_table_global_ijunc",
 ]
 IPX_OPT_COMBINE = 1
 
@@ -143,6 +144,8 @@ def load():
     lib.ipx_use_stream.argtypes = [vp, vp]
     lib.ipx_decode_bgzf.argtypes = [vp, C.POINTER(BgzfFile), C.POINTER(Batch)]
     lib.ipx_copy_async.argtypes = [vp, vp, vp, C.c_uint64]
+    lib.ipx_table_sorted_orders.argtypes = [vp, C.POINTER(Table), vp, C.c_uint64]
+    lib.ipx_table_global_ijunc.argtypes = [vp, C.POINTER(Table), vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     lib.ipx_records_export.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ipx_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ipx_profile.argtypes = [vp, C.c_int]

@@ -1556,6 +1556,62 @@ int ipx_copy_async(ipx_handle *h, void *dst, const void *src, uint64_t bytes) {
     return IPX_OK;
 }
 
+// ---- global sjN across key ranges (include/ipx.h, ABI 5) ----------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_sorted_orders(uint32_t n, const uint64_t *__restrict__ creator_order,
+                                                       const uint32_t *__restrict__ ijunc, uint64_t *__restrict__ out, uint64_t capacity) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * 256) {
+        if (i < n) out[ijunc[i]] = creator_order[i];          // the table's own ijunc is the rank of the order: a scatter sorts
+        else out[i] = ~0ull;
+    }
+}
+// the number of smaller orders in n_lists ascending lists (padded with ~0): one binary search per list
+__global__ __launch_bounds__(256) void k_global_ijunc(uint32_t n, const uint64_t *__restrict__ creator_order,
+                                                      const uint64_t *__restrict__ lists, uint32_t n_lists, uint64_t stride,
+                                                      uint64_t length, uint32_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t o = creator_order[i];
+        uint64_t rank = 0;
+        for (uint32_t l = 0; l < n_lists; ++l) {
+            const uint64_t *lst = lists + (uint64_t)l * stride;
+            uint64_t lo = 0, hi = length;                      // first element >= o
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (lst[mid] < o) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        out[i] = (uint32_t)rank;
+    }
+}
+}  // namespace
+
+int ipx_table_sorted_orders(ipx_handle *h, const ipx_table *table, uint64_t *out, uint64_t capacity) {
+    if (!h || !table || (capacity && !out)) return IPX_EINVAL;
+    if (table->memory != IPX_MEM_DEVICE) return fail(h, IPX_EINVAL, "ipx_table_sorted_orders: the table must be in device memory%s%ld", "", 0);
+    if (table->n_junctions > capacity) return fail(h, IPX_EINVAL, "ipx_table_sorted_orders: %s%ld junctions do not fit the list", "", (long)table->n_junctions);
+    (void)hipSetDevice(h->params.device);
+    if (!capacity) return IPX_OK;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(ipx_div_up(capacity, 256), 4096);
+    hipLaunchKernelGGL(k_sorted_orders, dim3(blocks), dim3(256), 0, h->stream, (uint32_t)table->n_junctions, table->creator_order,
+                       table->ijunc, out, capacity);
+    HIPCHK(hipGetLastError());
+    return IPX_OK;
+}
+
+int ipx_table_global_ijunc(ipx_handle *h, const ipx_table *table, const uint64_t *lists, uint32_t n_lists, uint64_t stride,
+                           uint64_t length, uint32_t *out_ijunc) {
+    if (!h || !table || length > stride || (table->n_junctions && (!lists || !out_ijunc || !n_lists))) return IPX_EINVAL;
+    if (table->memory != IPX_MEM_DEVICE) return fail(h, IPX_EINVAL, "ipx_table_global_ijunc: the table must be in device memory%s%ld", "", 0);
+    (void)hipSetDevice(h->params.device);
+    if (!table->n_junctions) return IPX_OK;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(ipx_div_up(table->n_junctions, 256), 4096);
+    hipLaunchKernelGGL(k_global_ijunc, dim3(blocks), dim3(256), 0, h->stream, (uint32_t)table->n_junctions, table->creator_order, lists,
+                       n_lists, stride, length, out_ijunc);
+    HIPCHK(hipGetLastError());
+    return IPX_OK;
+}
+
 // the splitters as the partition kernels want them (device copy, refreshed when they change)
 static int stage_splitters(ipx_handle *h, uint32_t n_parts, const uint64_t *splitters, unsigned long long **d_spl,
                            unsigned long long **d_cnt, unsigned long long **d_blk, uint32_t blocks) {

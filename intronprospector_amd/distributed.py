@@ -19,6 +19,7 @@ whose max-of-confidences rule differs from a single run over the same input.
 Everything here is plumbing on tables of at most a few million rows; torch ops
 are used so the same code runs on CPU tensors under gloo.
 """
+import ctypes as C
 import os
 
 import torch
@@ -434,19 +435,21 @@ class RecordExchanger:
         n = int(table.n_junctions) if failed is None else 0
         J = int(info.max_received) + 1
         cd = self.comm_device
-        co = torch.empty(n, dtype=torch.int64, device=self.device)
-        lij = torch.empty(n, dtype=torch.int32, device=self.device)
-        if n:
-            ex.copy_async(co.data_ptr(), table.creator_order, n * 8)
-            ex.copy_async(lij.data_ptr(), table.ijunc, n * 4)
-        mine = torch.full((J,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=self.device)
-        if failed is not None:
-            mine[0] = min(failed.order, (1 << 62))
-        mine[1:n + 1][lij.to(torch.int64)] = co   # scattering by the local rank sorts the orders without a sort
+        # (round 5: the sorted list and the ranking are libipx kernels, ipx_table_sorted_orders / ipx_table_global_ijunc --
+        # rounds 2-4 built them here from two copies, a scatter by index, a batched searchsorted and a sum)
+        mine = torch.empty(J, dtype=torch.int64, device=self.device)
+        empty = L.Table()
+        empty.memory = L.IPX_MEM_DEVICE
+        tab = table if n else empty
+        ex._check(ex.lib.ipx_table_sorted_orders(ex.h, C.byref(tab), mine.data_ptr() + 8, J - 1))
+        mine[0] = min(failed.order, (1 << 62)) if failed is not None else torch.iinfo(torch.int64).max
         parts = torch.empty((world, J), dtype=torch.int64, device=cd)
         dist.all_gather_into_tensor(parts.view(-1), mine.to(cd), group=self.group)
         parts = parts.to(self.device)
-        ijunc = torch.searchsorted(parts[:, 1:].contiguous(), co.unsqueeze(0).expand(world, -1).contiguous()).sum(dim=0)
+        ijunc = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            ex._check(ex.lib.ipx_table_global_ijunc(ex.h, C.byref(table), parts.data_ptr() + 8, world, J, J - 1, ijunc.data_ptr()))
+        ijunc = ijunc.to(torch.int64)
         self._last_trouble = (parts[:, 0].min(), failed)
         if self.strict:
             self.check_last()
@@ -548,22 +551,24 @@ class RecordExchanger:
         t0 = self._lap("finalize", t0)
         # 5. sjN numbering is global: rank of the creation order over all ranks' junctions
         n = int(table.n_junctions) if failed is None else 0
-        co = torch.empty(n, dtype=torch.int64, device=self.device)
-        if n:
-            ex._check(ex.lib.ipx_copy(ex.h, co.data_ptr(), table.creator_order, n * 8))
-        # the local ijunc is the rank inside this table: scattering by it sorts the orders without a sort; the
-        # global rank is the number of smaller orders in every rank's (sorted) list
-        lij = torch.empty(n, dtype=torch.int32, device=self.device)
-        if n:
-            ex._check(ex.lib.ipx_copy(ex.h, lij.data_ptr(), table.ijunc, n * 4))
-        co_sorted = torch.empty_like(co)
-        co_sorted[lij.to(torch.int64)] = co
-        co_c = self._to_comm(co)
-        # (rows filled up with the largest order: they stay sorted and the filling counts for nobody; one
-        # batched search instead of one per rank)
+        # the local ijunc is the rank inside this table: scattering by it sorts the orders without a sort
+        # (ipx_table_sorted_orders); the global rank is the number of smaller orders in every rank's (sorted) list
+        # (ipx_table_global_ijunc)
+        empty = L.Table()
+        empty.memory = L.IPX_MEM_DEVICE
+        co_sorted = torch.empty(n, dtype=torch.int64, device=self.device)
+        ex._check(ex.lib.ipx_table_sorted_orders(ex.h, C.byref(table if n else empty), co_sorted.data_ptr(), n))
+        torch.cuda.synchronize(self.device)      # (this form runs on the handle's own stream, torch's ops on torch's: the first batch only)
+        # (rows filled up with the largest order: they stay sorted and the filling counts for nobody)
         parts, _ = _all_gather_var(self._to_comm(co_sorted), self.group, failed or ShardError(),
                                        pad_value=torch.iinfo(torch.int64).max, stacked=True)
-        ijunc = torch.searchsorted(parts, co_c.unsqueeze(0).expand(parts.shape[0], -1).contiguous()).sum(dim=0)
+        parts = parts.to(self.device).contiguous()
+        ijunc = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            ex._check(ex.lib.ipx_table_global_ijunc(ex.h, C.byref(table), parts.data_ptr(), int(parts.shape[0]), int(parts.shape[1]),
+                                                    int(parts.shape[1]), ijunc.data_ptr()))
+            torch.cuda.synchronize(self.device)
+        ijunc = ijunc.to(torch.int64)
         t0 = self._lap("global_ijunc", t0)
         self._keep = (send, recv)        # the table arrays do not alias these, but keep them until the next run
         return table, ijunc

@@ -34,7 +34,7 @@ def test_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.ipx_abi_version() == 4
+    assert lib.ipx_abi_version() == 5
 
 
 def test_the_per_operation_scan_is_a_library_of_its_own():

@@ -284,12 +284,12 @@ def upload(batch, dev):
 
 
 def kernel_source_hash():
-    """sha256 over the device sources (csrc/*.hip, *.h): what profiles/traffic.json was measured on is stamped with it"""
+    """sha256 over the device sources (csrc/*.hip, *.h, *.inc): what profiles/traffic.json was measured on is stamped with it"""
     import glob
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "intronprospector_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc"))):
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:16]
 

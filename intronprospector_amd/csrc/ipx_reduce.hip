@@ -596,6 +596,66 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     }
 }
 
+// Without a genome every junction is valid, keeps its creator's strand and its place (ipx_launch_reduce: `identity`):
+// k_finish_junctions and k_emit_junctions are one pass over the junctions then.  The creation-order key packs the ordinal
+// in its full twenty bits (k_emit_junctions packs it in as many bits as the table's largest ordinal has, which it learns
+// from k_finish_junctions -- the one thing that kept the two apart; the rank's bitmap squeezes constant bits out anyway).
+__global__ __launch_bounds__(256) void k_finish_emit_identity(
+    uint32_t n_j, const uint32_t *__restrict__ jrank, const uint32_t *__restrict__ jstart, const uint32_t *__restrict__ jend,
+    const uint32_t *__restrict__ amin, const uint32_t *__restrict__ amax, const unsigned long long *__restrict__ counts,
+    const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jfirstbin, const uint32_t *__restrict__ tid_of_rank,
+    const uint32_t *n_valid_total, const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items,
+    uint32_t *__restrict__ rank_bits, uint32_t *__restrict__ jvalid, uint8_t *__restrict__ jstrand) {
+    __shared__ uint32_t bits_s[4][5];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
+    constexpr uint32_t ord_bits = 20;
+    uint32_t o0 = 0, o1 = 0, a0 = ~0u, a1 = ~0u, oo = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_j; j += gridDim.x * blockDim.x) {
+        const unsigned long long cr = creator[j];
+        const uint32_t s = IPX_ORD_STRAND(cr);
+        jvalid[j] = 1u;
+        jstrand[j] = (uint8_t)s;
+        out.target[j] = tid_of_rank[jrank[j]];
+        out.intron_start[j] = jstart[j];
+        out.intron_end[j] = jend[j];
+        out.anchor_start[j] = amin[j];
+        out.anchor_end[j] = amax[j];
+        out.strand[j] = (uint8_t)s;
+        out.motif[j] = 0;
+        out.read_counts[(uint64_t)j * 3 + 0] = counts[(uint64_t)j * 3 + 0];
+        out.read_counts[(uint64_t)j * 3 + 1] = counts[(uint64_t)j * 3 + 1];
+        out.read_counts[(uint64_t)j * 3 + 2] = counts[(uint64_t)j * 3 + 2];
+        out.creator_order[j] = IPX_ORD_SEQ(cr);
+        out.hist_begin[j] = jfirstbin[j];
+        const uint32_t ordinal = (uint32_t)(cr >> IPX_ORD_SHIFT_ORDINAL) & IPX_ORD_MAX_ORDINAL;
+        const unsigned long long rk = (IPX_ORD_READ(cr) << ord_bits) | ordinal;
+        rank_items[j] = make_uint4((uint32_t)rk, (uint32_t)(rk >> 32), 0u, j);
+        oo |= ordinal;
+        o0 |= (uint32_t)rk; o1 |= (uint32_t)(rk >> 32);
+        a0 &= (uint32_t)rk; a1 &= (uint32_t)(rk >> 32);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        o0 |= __shfl_xor(o0, d); o1 |= __shfl_xor(o1, d); oo |= __shfl_xor(oo, d);
+        a0 &= __shfl_xor(a0, d); a1 &= __shfl_xor(a1, d);
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) { bits_s[wave][0] = o0; bits_s[wave][1] = o1; bits_s[wave][2] = a0; bits_s[wave][3] = a1; bits_s[wave][4] = oo; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const uint32_t k = threadIdx.x;
+        if (k < 2) {
+            const uint32_t v = bits_s[0][k] | bits_s[1][k] | bits_s[2][k] | bits_s[3][k];
+            if (v) atomicOr(&rank_bits[1 + k], v);
+        } else if (k < 4) {
+            const uint32_t v = bits_s[0][k] & bits_s[1][k] & bits_s[2][k] & bits_s[3][k];
+            if (v != ~0u) atomicAnd(&rank_bits[1 + k], v);
+        } else {
+            const uint32_t v = bits_s[0][4] | bits_s[1][4] | bits_s[2][4] | bits_s[3][4];
+            if (v) atomicOr(&rank_bits[0], v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_emit_ijunc(uint32_t n, const uint4 *__restrict__ items,
                                                     uint32_t *__restrict__ ijunc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -738,6 +798,16 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                                rb.jmotif, sj_filter, rb.first, rb.creator, rb.counts, rb.amin, rb.amax, rb.bin_count, counters, HeadOut{});
         ipx_prof_mark(s, IPXK_PHASE_B);
     }
+    TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
+                rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
+                rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
+    if (identity) {
+        hipLaunchKernelGGL(k_finish_emit_identity, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.jrank,
+                           rb.jstart, rb.jend, rb.amin, rb.amax, rb.counts, rb.creator, rb.jfirstbin, tid_of_rank, rb.totals + 0,
+                           rb.totals + 1, td, rb.rank_a, rb.totals + 2, rb.jvalid, rb.jstrand);
+        ipx_prof_mark(s, IPXK_EMIT_J);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_finish_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.first, rb.creator,
                        rb.jmotif, rb.jvalid, rb.jstrand, counters, rb.totals + 2);
     ipx_prof_mark(s, IPXK_FINISH_J);
@@ -753,9 +823,6 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                            rb.bin_pos, rb.out_hist_value, rb.out_hist_count, identity);
         ipx_prof_mark(s, IPXK_EMIT_BINS);
     }
-    TableDev td{rb.out_target, rb.out_intron_start, rb.out_intron_end, rb.out_anchor_start,
-                rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
-                rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
     hipLaunchKernelGGL(k_emit_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
                        rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a, rb.totals + 2, identity);

@@ -302,7 +302,14 @@ int ipx_host_free(void *p);
  * which alignment and why (the earliest one in input order).  The reference
  * throws at that alignment and its caller never sees a table; *out is then
  * filled from the records of all other alignments and has no reference
- * counterpart. */
+ * counterpart.
+ * Which sort: LSD radix passes, or -- from 16 M records on -- a bucket sort whose leaves are sorted in LDS.  The leaf
+ * sort takes an item's rank among the equal digits of its wave from the value an LDS returning atomic hands back, i.e.
+ * it rests on lanes of one instruction that hit the same LDS word being served in lane order: measured (1.3 x 10^10
+ * lane-operations without an exception, profiles/microbench/lds_atomic_order.hip), checked again at start-up in every
+ * process (the bucket sort stays off if the check fails), NOT a documented property of the hardware.  Every sort is
+ * followed by a check that neighbouring items ascend, and a table is never reduced from items that do not: they are
+ * sorted again by the radix passes.  IPX_SORT=lsd in the environment never takes the bucket sort. */
 int ipx_finalize(ipx_handle *h, int32_t memory, ipx_table *out);
 
 /* JunctionsExtractor::clear(), junctions_extractor.hh:223-225: drops records and

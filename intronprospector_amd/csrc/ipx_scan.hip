@@ -1008,15 +1008,21 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(const Long3Args args) {
         // anchor, from LIMBO the left one (:232-255) -- k_scan_long's step for exactly this case.  Lanes that are in
         // LEFT / RIGHT (three in four: they did not stop) take a plain op in the same step
         uint32_t ind_acc = 0, mm_acc = 0;                           // what the plain ops add to the current side's counters
-        // bit 0: moves along the reference (M = X D), bit 1: indel (I D), bit 2: M = X, bit 3: X; 0: not a plain op
-        constexpr unsigned long long PLAIN_CODES = 0x0000000D50000325ull;
+        // An op's classes as masks (all ones / zero), one v_bfe_i32 each: bit `op` of a 16-bit pattern (BAM's "MIDNSHP=X":
+        // M 0, I 1, D 2, = 7, X 8) -- the pattern stands twice in the word, so the WHOLE CIGAR word can be the bit offset
+        // (the instruction reads its bits 4:0; bit 4 is the length's lowest).  A plain op is one with m_adv | m_id.
+        // (Rounds 2-4 shifted a 64-bit table of four-bit codes by 4 * op and took the code apart: ten instructions for
+        // these four, and the steps below hung on a branch each)
+        constexpr uint32_t K_ADV = 0x01850185u,     // moves along the reference: M D = X
+                           K_ID = 0x00060006u,      // indel: I D
+                           K_M = 0x01810181u,       // M = X
+                           K_X = 0x01000100u;       // X
         {
             const uint32_t w = my_ring[cw & (LONG3_RINGW - 1u)][lane];
-            const uint32_t op = w & 0xfu, len = w >> 4;
-            const uint32_t code = (uint32_t)(PLAIN_CODES >> (op * 4u));
-            const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
-                           m_m = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
-            const bool may = cw < lim1 && (code & 0xfu) != 0u;
+            const uint32_t len = w >> 4;
+            const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)K_ADV, w, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)K_ID, w, 1),
+                           m_m = (uint32_t)__builtin_amdgcn_sbfe((int)K_M, w, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)K_X, w, 1);
+            const bool may = cw < lim1 && (m_adv | m_id) != 0u;
             const bool ok_e = may && m_m != 0u && (state & (ST_LIMBO | ST_INTRON)) != 0u;
             const uint32_t il = len & m_id;
             const uint32_t ci = (cur_indel + il) & ~m_m;
@@ -1052,32 +1058,32 @@ __global__ __launch_bounds__(256, 3) void k_scan_long3(const Long3Args args) {
             const uint32_t lim = lr ? lim1 : 0u;
             const uint32_t m_l = state == ST_LEFT ? ~0u : 0u;
             // The words of all the plain steps are read up front, from cw on: a step that does not apply leaves cw where it
-            // is, and so do all the steps behind it (the same word fails the same way), so step k applies exactly if it
-            // finds cw == cw0 + k -- with the word read at the step, from an address that depends on the step before, a
-            // turn was six dependent trips to LDS (round 5)
+            // is, and so do all the steps behind it (the same word fails the same way), so step k applies exactly if all
+            // before it did (`ok` runs through the steps) -- with the word read at the step, from an address that depends on
+            // the step before, a turn was six dependent trips to LDS (round 5).  The steps are straight-line code: what an
+            // op adds is masked by its classes and by `ok`
             const uint32_t cw0 = cw;
             uint32_t wk[LONG3_FAST];
 #pragma unroll
             for (uint32_t k = 0; k < LONG3_FAST; ++k) wk[k] = my_ring[(cw0 + k) & (LONG3_RINGW - 1u)][lane];
+            const uint32_t nmax = lim > cw0 ? lim - cw0 : 0u;            // plain steps the lane may take this turn
+            bool ok = true;
 #pragma unroll
             for (uint32_t k = 0; k < LONG3_FAST; ++k) {
                 const uint32_t w = wk[k];
-                const uint32_t op = w & 0xfu, len = w >> 4;
-                const uint32_t code = (uint32_t)(PLAIN_CODES >> (op * 4u));
-                const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)code, 0, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)code, 1, 1),
-                               m_m = (uint32_t)__builtin_amdgcn_sbfe((int)code, 2, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)code, 3, 1);
-                const uint32_t tpn = tp + (len & m_adv);
-                const uint32_t il = len & m_id;
-                const uint32_t ci = (cur_indel + il) & ~m_m;             // I/D :257-275 add up, M = X :232-255 start over
-                const bool ok = cw == cw0 + k && cw < lim && (code & 0xfu) != 0u && ci <= p.max_anchor_indel_size;
-                if (ok) {
-                    tp = tpn;
-                    ae = (tpn & m_m) | (ae & ~m_m);
-                    cur_indel = ci;
-                    ind_acc += il;
-                    mm_acc += len & m_x;
-                    cw += 1u;
-                }
+                const uint32_t len = w >> 4;
+                const uint32_t m_adv = (uint32_t)__builtin_amdgcn_sbfe((int)K_ADV, w, 1), m_id = (uint32_t)__builtin_amdgcn_sbfe((int)K_ID, w, 1),
+                               m_m = (uint32_t)__builtin_amdgcn_sbfe((int)K_M, w, 1), m_x = (uint32_t)__builtin_amdgcn_sbfe((int)K_X, w, 1);
+                const uint32_t ci = (cur_indel + (len & m_id)) & ~m_m;   // I/D :257-275 add up, M = X :232-255 start over
+                // a step that does not apply stops all the steps behind it
+                ok = ok && k < nmax && (m_adv | m_id) != 0u && ci <= p.max_anchor_indel_size;
+                const uint32_t le = ok ? len : 0u;
+                tp += le & m_adv;
+                ae = (ok && m_m != 0u) ? tp : ae;
+                cur_indel = ok ? ci : cur_indel;
+                ind_acc += le & m_id;
+                mm_acc += le & m_x;
+                cw += ok ? 1u : 0u;
 #ifdef IPX_LONG3_STATS
                 st_plain += __popcll(ipx_ballot(ok));
 #endif
@@ -1221,11 +1227,10 @@ __device__ __forceinline__ uint32_t *defer_counter(Counters *c) {
 
 #include "ipx_scan_short.inc"
 
-// ---- what k_scan_short left out ------------------------------------------------------------------
-// k_scan_rest: the alignments k_scan_short listed (more than 8 CIGAR ops; every alignment of a tile whose
-// records overflowed the LDS pool), one lane each, op by op: count (run_read<0>), ONE reservation per wave,
-// store (run_read<1>).  Launched only when the first stage listed something (ipx_launch_scan_rest): even an
-// empty launch of its 1024 blocks costs 18 us.
+// ---- what k_scan_short3 leaves out -----------------------------------------------------------------
+// k_scan_rest: the alignments k_scan_short3 listed (more than 8 CIGAR ops in a batch of short ones), one lane each,
+// op by op: count (run_read<0>), ONE reservation per wave, store (run_read<1>).  It reads the list's length on the
+// device and leaves at once if it is zero; its grid follows what the previous batch listed (see the launch below).
 __global__ __launch_bounds__(256) void k_scan_rest(ScanParams p, AlnArrays a, const uint32_t *__restrict__ cigar,
                                                    const uint32_t *__restrict__ defer,
                                                    uint4 *__restrict__ items, uint4 *__restrict__ pays,
@@ -1494,8 +1499,8 @@ hipError_t ipx_launch_scan(hipStream_t s, ScanParams p, const ipx_batch &b,
                                b.cigar_off, b.n_cigar, b.cigar, tail, rank_of_tid, items, pays, cnts, digs, capacity, counters);
     }
     if (short_reads) {
-        // Second stage, in the same breath: the alignments k_scan_short only listed (more than 8 ops, tiles whose
-        // records overflowed the pool) are walked op by op by k_scan_rest, which reads the list's length on the
+        // Second stage, in the same breath: the alignments k_scan_short3 only listed (more than 8 ops) are walked
+        // op by op by k_scan_rest, which reads the list's length on the
         // device and leaves at once if it is zero.  Its grid follows what the previous batch listed (rest_hint):
         // round 1 had the host read the count back and launch it with a fitting grid -- a second read-back and a
         // second closing of the stripes on every batch that listed anything (S: 35 us of a 0.74 ms step for 512

@@ -86,10 +86,10 @@ def test_short_reads_in_random_order_match_oracle():
     assert np.array_equal(sorted_ora["counts"], ora["counts"]) and not np.array_equal(sorted_ora["ijunc"], ora["ijunc"])
 
 
-@pytest.mark.parametrize("n_reads", [511, 512, 513, 1023, 1025, 512 * 37 + 1, 512 * 40 - 1])
+@pytest.mark.parametrize("n_reads", [127, 128, 129, 511, 512, 513, 1023, 1025, 128 * 9 + 1, 512 * 37 + 1, 512 * 40 - 1])
 def test_ragged_last_tile_of_the_short_read_scan(n_reads):
-    """k_scan_short works in tiles of 512 alignments whose fields are fetched from a CLAMPED index: a batch that ends one
-    alignment before, at, or after a tile boundary must count every read once and none twice (review of round 3, item 1)."""
+    """The short-read scan works in tiles (a wave's 128 alignments, a block's 512; rounds 1-4: 512 per block) whose fields
+    are fetched from a CLAMPED index: a batch that ends one alignment before, at, or after a tile boundary must count every read once and none twice (review of round 3, item 1)."""
     from intronprospector_amd import synth
     batch, names, _ = synth.short_reads(n_reads, seed=700 + n_reads % 97, n_targets=2, target_len=2_800_000, n_sites=60)
     dev, ora, err = _run_both(batch, names, {})
@@ -422,7 +422,7 @@ def test_striped_append_with_uneven_stripes_and_capacity_retry():
 
 
 def test_clipped_and_unspliced_short_cigars(monkeypatch):
-    """k_scan_short's phase 1 beyond "aM nN bM": one S or H clip in front and / or at the end keeps the closed forms;
+    """The short-read scan's closed forms beyond "aM nN bM": one S or H clip in front and / or at the end keeps the closed forms;
     up to four ops without an N are dropped without a walk (unless one of them is an op the walk throws on); everything
     else -- two clips in a row, = and X, indels next to introns -- waits for a walk pass.  All of it against the oracle,
     in sorted order, several tiles' worth, with min-anchor / intron limits that reject some."""
@@ -472,10 +472,9 @@ def test_clipped_and_unspliced_short_cigars(monkeypatch):
 
 
 def test_short_cigar_tiles_that_overflow_the_record_pool(monkeypatch):
-    """Three junctions per alignment: a tile of 512 alignments emits 1536 records, more than the 768 the
-    LDS pool of k_scan_short holds -> the tile's alignments are listed and walked by the second stage
-    (k_scan_rest: count / reserve / store), here together with the striped append (>= 64 blocks) and with
-    a tail of ordinary alignments in the same launch."""
+    """Three junctions per alignment: far more records per tile than the scan's LDS pool holds (rounds 1-4: 768 per
+    block, and the tile went to k_scan_rest; round 5: 80 per wave, flushed as often as it fills), here together with
+    the striped append (>= 64 blocks) and with a tail of ordinary alignments in the same launch."""
     from intronprospector_amd import synth
     monkeypatch.setenv("IPX_SHORT_MAX_AVG", "16")          # 5.6 words per alignment go there anyway; be explicit
     rng = np.random.default_rng(95)

@@ -3,6 +3,7 @@
 #   1  bench lines (default with configs and CPU baseline; shuffled; M1), rocprofv3 kernel stats of S / G / L
 #   2  SQ counters of S and G, PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of S / G / L -> traffic.json
 #   3  run-to-run consistency, the exchange rehearsal, the group lines, the command line
+#   4  part 2 again, then the driver's command with the fresh traffic.json in place
 # Outputs under gpurun_out/r05m/.
 set -e
 cd "$GRAFT_REPO_ROOT"
@@ -42,6 +43,13 @@ if [ "$PART" = 2 ]; then
     echo progress: pmc $W
   done
   rm -rf $O/pmc_?_fetch $O/pmc_?_write
+fi
+if [ "$PART" = 4 ]; then
+  # after a change to the kernel sources: the PMC traffic again (the stamp in traffic.json must be the sources'), then the
+  # driver's command with that traffic.json in place, so that the line carries roofline.traffic
+  bash profiles/r05_measure.sh 2
+  cp $O/traffic.json profiles/traffic.json
+  python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo progress: default line with traffic
 fi
 if [ "$PART" = 3 ]; then
   python profiles/consistency.py S G L Sshuf M --rounds 40 > $O/consistency.txt 2>&1; echo progress: consistency

@@ -60,6 +60,25 @@ def test_group_of_members_sharing_the_gpu_equals_oracle(members, genome, oracle_
     grp.close()
 
 
+def test_group_numbers_sjN_by_a_merge_in_ranges(oracle_lib):
+    """Enough junctions (>= 4096) for ipx_group_finalize to cut the merge of its members' creation orders into ranges
+    of the order axis, a thread each: the run-wide sjN must be the oracle's, junction by junction."""
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    batch, names, _ = synth.short_reads(150_000, seed=66, n_targets=4, target_len=6_000_000, n_sites=9000)
+    grp = ipa.JunctionsExtractorGroup([0, 0, 0], targets=names)
+    n = len(batch["tid"])
+    for a, b in ((0, n // 4), (n // 4, n)):
+        grp.push(synth.slice_batch(batch, a, b))
+    dev = grp.get_junctions()
+    ref, err = _oracle(batch, names)
+    assert err is None and "error" not in dev
+    assert len(ref["ijunc"]) >= 4096
+    helpers.compare_tables(dev, ref, None)
+    assert np.array_equal(np.sort(np.asarray(dev["ijunc"]).astype(np.int64)), np.arange(len(ref["ijunc"])))
+    grp.close()
+
+
 def test_group_members_fed_from_device_memory(oracle_lib):
     """ipx_group_push_member: the caller shards, every member takes its share from (its own) device memory -- how a
     step of the group is timed on resident input"""

@@ -390,7 +390,7 @@ int reset_counters(ipx_handle *h) {
 
 int grow_records(ipx_handle *h, uint64_t cap) {
     if (cap <= h->rec_cap) return IPX_OK;
-    if (cap >= (1ull << 32)) return fail(h, IPX_EINVAL, "more than 2^32-1 junction records in one table%s%ld", "", 0);
+    if (cap > IPX_MAX_RECORDS) return fail(h, IPX_EINVAL, "more than 2^31-1 junction records in one table%s%ld", "", 0);
     int rc;
     if ((rc = ensure(h, h->items_a, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
     if ((rc = ensure(h, h->pays, cap * sizeof(uint4), true, h->n_records * sizeof(uint4)))) return rc;
@@ -398,6 +398,7 @@ int grow_records(ipx_handle *h, uint64_t cap) {
     if ((rc = ensure(h, h->dig_a, cap + 64, true, h->n_records))) return rc;
     h->rec_cap = std::min(std::min(std::min(h->items_a.cap, h->pays.cap) / sizeof(uint4), h->cnts.cap / sizeof(uint32_t)),
                           h->dig_a.cap - 64);
+    h->rec_cap = std::min<uint64_t>(h->rec_cap, IPX_MAX_RECORDS);       // an item's index word has 31 bits
     return IPX_OK;
 }
 
@@ -1445,7 +1446,7 @@ int ipx_records_export(ipx_handle *h, ipx_record *dst, uint64_t capacity, uint64
     HIPCHK(ipx_stream_wait(h->stream));
     for (uint64_t i = 0; i < n; ++i) {
         const uint32_t *it = &items[4 * i];
-        const uint32_t *py = &pays[4 * (uint64_t)it[3]];         // item.w = index of the record's payload
+        const uint32_t *py = &pays[4 * (uint64_t)IPX_ITEM_INDEX(it[3])];         // item.w = index of the record's payload
         uint32_t rank;
         ipx_record &r = dst[i];
         unpack_key_host(it, h->key, rank, r.intron_start, r.intron_end, r.read_offset);

@@ -158,15 +158,17 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ 
             // some and a second all-to-all brings them over; without a spill they are not sent and the caller repeats)
             if (ok && (slot_records == 0 || pos < ((unsigned long long)part + 1) * slot_records)) {      // (a slot's header lies below its first position)
                 // on the way the item's fourth word (the record index, meaningless elsewhere) carries the count word
-                const uint4 py = pays[it.w];
-                it.w = cnts[it.w];
+                const uint32_t ri = IPX_ITEM_INDEX(it.w);
+                const uint4 py = pays[ri];
+                it.w = (it.w & IPX_ITEM_FOLDED) ? cnts[ri] : IPX_CNT_ONE(py.x & 3u);
                 out[2 * pos] = it;
                 out[2 * pos + 1] = py;
             } else if (ok && spill) {
                 const unsigned long long at = spill_base[part] + (pos - ((unsigned long long)part + 1) * slot_records);
                 if (at < spill_records) {         // (the caller gives room for every record; a smaller spill loses the rest -- its header says overflow all the same)
-                    const uint4 py = pays[it.w];
-                    it.w = cnts[it.w];
+                    const uint32_t ri = IPX_ITEM_INDEX(it.w);
+                    const uint4 py = pays[ri];
+                    it.w = (it.w & IPX_ITEM_FOLDED) ? cnts[ri] : IPX_CNT_ONE(py.x & 3u);
                     spill[2 * at] = it;
                     spill[2 * at + 1] = py;
                 }
@@ -280,9 +282,10 @@ __global__ __launch_bounds__(256) void k_adopt_slots(const uint4 *__restrict__ r
         cnts[idx] = it.w;
         const uint32_t reads = (it.w & IPX_CNT_MASK) + ((it.w >> IPX_CNT_BITS) & IPX_CNT_MASK) + (it.w >> (2 * IPX_CNT_BITS));
         extra += reads ? reads - 1u : 0u;
-        it.w = (uint32_t)idx;
+        const uint4 py = src[2 * i + 1];
+        it.w = (uint32_t)idx | (it.w != IPX_CNT_ONE(py.x & 3u) ? IPX_ITEM_FOLDED : 0u);
         items[idx] = it;
-        pays[idx] = src[2 * i + 1];
+        pays[idx] = py;
         digs[idx] = (uint8_t)ipx_digit_of(it, first);
         v[0] |= it.x; v[1] |= it.y; v[2] |= it.z;
         v[3] &= it.x; v[4] &= it.y; v[5] &= it.z;
@@ -328,9 +331,10 @@ __global__ __launch_bounds__(256) void k_adopt(const uint4 *__restrict__ rec, ui
         cnts[idx] = it.w;
         const uint32_t reads = (it.w & IPX_CNT_MASK) + ((it.w >> IPX_CNT_BITS) & IPX_CNT_MASK) + (it.w >> (2 * IPX_CNT_BITS));
         extra += reads ? reads - 1u : 0u;
-        it.w = (uint32_t)idx;
+        const uint4 py = rec[2 * i + 1];
+        it.w = (uint32_t)idx | (it.w != IPX_CNT_ONE(py.x & 3u) ? IPX_ITEM_FOLDED : 0u);
         items[idx] = it;
-        pays[idx] = rec[2 * i + 1];
+        pays[idx] = py;
         digs[idx] = (uint8_t)ipx_digit_of(it, first);
         v[0] |= it.x; v[1] |= it.y; v[2] |= it.z;
         v[3] &= it.x; v[4] &= it.y; v[5] &= it.z;

@@ -280,7 +280,8 @@ struct HeadOut {
 };
 
 // HAS_CNTS false: no record of the table stands for several (nothing combined, nothing adopted with counts), the count
-// word is IPX_CNT_ONE of the record's category and cnts is not read: one random 128-byte line per record less
+// word is IPX_CNT_ONE of the record's category and cnts is not read: one random 128-byte line per record less.  HAS_CNTS
+// true: the same for every record whose item does not carry IPX_ITEM_FOLDED (round 5)
 template <int MODE, bool HAS_CNTS>
 __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ items, uint64_t n,
                                                 const uint4 *__restrict__ pays,
@@ -337,9 +338,11 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
         uint32_t counted = 0;
         unsigned long long poison = NONE64;
         if (h.ok) {
-            const uint4 p = pays[h.it.w];
-            // reads per category this record stands for (one, unless the scan combined a tile's copies of it)
-            const uint32_t cw = (MODE != 1) ? (HAS_CNTS ? cnts[h.it.w] : IPX_CNT_ONE(p.x & 3u)) : 0u;
+            const uint32_t ri = IPX_ITEM_INDEX(h.it.w);
+            const uint4 p = pays[ri];
+            // reads per category this record stands for: one, unless the scan folded copies of it into it -- the item says
+            // so (IPX_ITEM_FOLDED), and only then is the count word worth its random line
+            const uint32_t cw = (MODE != 1) ? ((HAS_CNTS && (h.it.w & IPX_ITEM_FOLDED)) ? cnts[ri] : IPX_CNT_ONE(p.x & 3u)) : 0u;
             const unsigned long long ord = (unsigned long long)p.x | ((unsigned long long)p.y << 32);
             bool cnt_it = true;
             if (MODE == 1) {

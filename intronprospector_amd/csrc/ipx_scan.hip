@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(CLOSE_BT) void k_close(Counters *counters, uint64_t
                 src = base + (P0 > n ? P0 : n) + (i - tpre[ct]);
             }
             uint4 v = items[src];
-            v.w = (uint32_t)dst;
+            v.w = (v.w & IPX_ITEM_FOLDED) | (uint32_t)dst;
             items[dst] = v;
             pays[dst] = pays[src];
             cnts[dst] = cnts[src];

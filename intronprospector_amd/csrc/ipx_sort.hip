@@ -53,13 +53,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
             const uint32_t x = it & 7u, k = it >> 3, q = n_groups >> 3, r = n_groups & 7u;
             group = x * q + (x < r ? x : r) + k;
         }
-#pragma unroll
-        for (uint32_t g = 0; g < GROUP; ++g) hs[g][threadIdx.x] = 0;
-        __syncthreads();
         const uint32_t tile0 = group * GROUP;
+        // (the digit bytes are asked for BEFORE the counters are cleared and the block meets at the barrier: the kernel is
+        // a chain of latencies -- 5 us a launch on S, eight launches a sort -- and this link overlaps for free)
+        uint32_t v[BYTES ? GROUP : 1][BYTES ? WPT : 1];
+        bool whole[BYTES ? GROUP : 1];
         if (BYTES) {
-            uint32_t v[GROUP][WPT];
-            bool whole[GROUP];
 #pragma unroll
             for (uint32_t g = 0; g < GROUP; ++g) {
                 const uint64_t i0 = (uint64_t)(tile0 + g) * TILE + (uint64_t)threadIdx.x * BPT;
@@ -73,6 +72,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
                     v[g][0] = x.x; v[g][1] = x.y; v[g][WPT - 2] = x.z; v[g][WPT - 1] = x.w;
                 }
             }
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < GROUP; ++g) hs[g][threadIdx.x] = 0;
+        __syncthreads();
+        if (BYTES) {
 #pragma unroll
             for (uint32_t g = 0; g < GROUP; ++g) {
                 uint32_t *h = hs[g];
@@ -120,36 +124,51 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint4 *__restrict__
     }
 }
 
-// block b: hist[b][0..n_tiles) -> exclusive prefix in place, bin_total[b] = sum
+// inclusive prefix sum over the 64 lanes: DPP row shifts and row broadcasts, six v_add_u32_dpp (the __shfl_up form is six
+// dependent ds_bpermute round trips, ~100 cycles each)
+__device__ __forceinline__ uint32_t sort_wave_incl_scan(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// block b: hist[b][0..n_tiles) -> exclusive prefix in place, bin_total[b] = sum.  A thread owns `e` consecutive entries
+// of a round (e = 4, 8, 12 or 16: a round covers up to 4096 tiles, i.e. 16 M records), all of them loaded before the
+// first is used, and the wave's prefix is a DPP scan: ONE round for every table up to 16 M records where rounds of 1024
+// entries with six ds_bpermute trips each took 4.5 us at 1131 tiles and 9 us at 2405 (round 5; eight launches a sort)
 __global__ __launch_bounds__(256) void k_binscan(uint32_t *__restrict__ hist, uint32_t n_tiles,
                                                  uint32_t *__restrict__ bin_total) {
-    __shared__ uint32_t ws[4];
+    constexpr uint32_t E = 16;
+    __shared__ uint32_t ws[2][4];
     uint32_t *row = hist + (uint64_t)blockIdx.x * n_tiles;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
-        const uint32_t i = base + threadIdx.x * 4;
-        uint32_t v[4];
+    uint32_t carry = 0, par = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256 * E, par ^= 1u) {
+        const uint32_t left = n_tiles - base;
+        const uint32_t e = left >= 256 * E ? E : (((left + 255u) / 256u + 3u) & ~3u);      // block-uniform
+        const uint32_t i = base + threadIdx.x * e;
+        uint32_t v[E];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) v[k] = (i + k < n_tiles) ? row[i + k] : 0;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = mine;
+        for (uint32_t k = 0; k < E; ++k) v[k] = (k < e && i + k < n_tiles) ? row[i + k] : 0u;
+        uint32_t mine = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t x = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += x;
-        }
-        __syncthreads();
-        if (lane == 63) ws[wave] = incl;
-        __syncthreads();
+        for (uint32_t k = 0; k < E; ++k) mine += v[k];
+        const uint32_t incl = sort_wave_incl_scan(mine);
+        if (lane == 63) ws[par][wave] = incl;
+        __syncthreads();                       // (one barrier a round: the rounds alternate between two sets of wave sums)
         uint32_t off = carry + incl - mine;
-        for (uint32_t w = 0; w < wave; ++w) off += ws[w];
+        for (uint32_t w = 0; w < wave; ++w) off += ws[par][w];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (i + k < n_tiles) row[i + k] = off;
+        for (uint32_t k = 0; k < E; ++k) {
+            if (k < e && i + k < n_tiles) row[i + k] = off;
             off += v[k];
         }
-        carry += ws[0] + ws[1] + ws[2] + ws[3];
+        carry += ws[par][0] + ws[par][1] + ws[par][2] + ws[par][3];
     }
     if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
@@ -199,12 +218,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, u
     if (t < 256) {
         my_total = bin_total[t];
         my_before = scanned[(uint64_t)t * n_tiles + tile_id];
-        incl2 = my_total;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t x = __shfl_up(incl2, o);
-            if ((int)lane >= o) incl2 += x;
-        }
+        incl2 = sort_wave_incl_scan(my_total);
         if (lane == 63) wsum2[wave] = incl2;
     }
     __syncthreads();
@@ -253,12 +267,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, u
             run += c;
         }
         tot = run;
-        incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += v;
-        }
+        incl = sort_wave_incl_scan(tot);
         if (lane == 63) wsum[wave] = incl;
     }
     __syncthreads();
@@ -297,12 +306,7 @@ __global__ __launch_bounds__(NT) void k_scatter(const uint4 *__restrict__ src, u
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *total) {
     __shared__ uint32_t ws[4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t x = __shfl_up(incl, o);
-        if ((int)lane >= o) incl += x;
-    }
+    const uint32_t incl = sort_wave_incl_scan(v);
     __syncthreads();               // ws may still be read by a previous call
     if (lane == 63) ws[wave] = incl;
     __syncthreads();
@@ -413,12 +417,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(ScanJob a, ScanJob b) {
 #pragma unroll
         for (uint32_t k = 0; k < 16; ++k) s[j] += v[j][k];
     }
-    uint32_t incl[2] = {s[0], s[1]};
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t x0 = __shfl_up(incl[0], o), x1 = __shfl_up(incl[1], o);
-        if ((int)lane >= o) { incl[0] += x0; incl[1] += x1; }
-    }
+    const uint32_t incl[2] = {sort_wave_incl_scan(s[0]), sort_wave_incl_scan(s[1])};
     if (lane == 63) { ws[0][wave] = incl[0]; ws[1][wave] = incl[1]; }
     __syncthreads();
 #pragma unroll

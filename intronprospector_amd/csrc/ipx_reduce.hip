@@ -471,14 +471,14 @@ __global__ __launch_bounds__(256, 8) void k_reduce(const uint4 *__restrict__ ite
 
 // per junction: validity, final strand, genome errors.  Grid-stride with few blocks: the OR of the
 // creators' ordinals leaves each block as ONE atomic (same-address atomics serialise at ~17 ns).
-__global__ __launch_bounds__(256) void k_finish_junctions(uint32_t n_j,
+__global__ __launch_bounds__(1024) void k_finish_junctions(uint32_t n_j,
                                                           const unsigned long long *__restrict__ first,
                                                           const unsigned long long *__restrict__ creator,
                                                           const uint32_t *__restrict__ jmotif,
                                                           uint32_t *__restrict__ jvalid,
                                                           uint8_t *__restrict__ jstrand,
                                                           Counters *counters, uint32_t *__restrict__ ord_or) {
-    __shared__ uint32_t or_s[4];
+    __shared__ uint32_t or_s[16];
     uint32_t o = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_j; j += gridDim.x * blockDim.x) {
         const uint32_t m = jmotif[j];
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256) void k_finish_junctions(uint32_t n_j,
     if ((threadIdx.x & 63u) == 0) or_s[threadIdx.x >> 6] = o;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t all = or_s[0] | or_s[1] | or_s[2] | or_s[3];
+        uint32_t all = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) all |= or_s[w];
         if (all) atomicOr(ord_or, all);
     }
 }
@@ -542,7 +543,7 @@ struct TableDev {
     uint32_t *ijunc;
 };
 
-__global__ __launch_bounds__(256) void k_emit_junctions(
+__global__ __launch_bounds__(1024) void k_emit_junctions(
     uint32_t n_j, const uint32_t *__restrict__ jvalid, const uint32_t *__restrict__ jpos,
     const uint32_t *__restrict__ jrank, const uint32_t *__restrict__ jstart,
     const uint32_t *__restrict__ jend, const uint32_t *__restrict__ amin,
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     const uint32_t *__restrict__ tid_of_rank, const uint32_t *n_valid_total,
     const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items, uint32_t *__restrict__ rank_bits,
     uint32_t identity) {
-    __shared__ uint32_t bits_s[4][4];
+    __shared__ uint32_t bits_s[16][4];
     if (blockIdx.x == 0 && threadIdx.x == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
     // creation order packed as read_index << (bits of the largest ordinal) | ordinal; the OR / AND of those
     // keys (rank_bits[1..4]) tell the host which bytes vary, i.e. which radix passes the ranking needs
@@ -588,14 +589,11 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
     if ((threadIdx.x & 63u) == 0) { bits_s[wave][0] = o0; bits_s[wave][1] = o1; bits_s[wave][2] = a0; bits_s[wave][3] = a1; }
     __syncthreads();
     if (threadIdx.x < 4) {
-        const uint32_t k = threadIdx.x;
-        if (k < 2) {
-            const uint32_t v = bits_s[0][k] | bits_s[1][k] | bits_s[2][k] | bits_s[3][k];
-            if (v) atomicOr(&rank_bits[1 + k], v);
-        } else {
-            const uint32_t v = bits_s[0][k] & bits_s[1][k] & bits_s[2][k] & bits_s[3][k];
-            if (v != ~0u) atomicAnd(&rank_bits[1 + k], v);
-        }
+        const uint32_t k = threadIdx.x, nw = blockDim.x >> 6;
+        uint32_t v = k < 2 ? 0u : ~0u;
+        for (uint32_t w = 0; w < nw; ++w) v = k < 2 ? (v | bits_s[w][k]) : (v & bits_s[w][k]);
+        if (k < 2) { if (v) atomicOr(&rank_bits[1 + k], v); }
+        else if (v != ~0u) atomicAnd(&rank_bits[1 + k], v);
     }
 }
 
@@ -603,13 +601,13 @@ __global__ __launch_bounds__(256) void k_emit_junctions(
 // k_finish_junctions and k_emit_junctions are one pass over the junctions then.  The creation-order key packs the ordinal
 // in its full twenty bits (k_emit_junctions packs it in as many bits as the table's largest ordinal has, which it learns
 // from k_finish_junctions -- the one thing that kept the two apart; the rank's bitmap squeezes constant bits out anyway).
-__global__ __launch_bounds__(256) void k_finish_emit_identity(
+__global__ __launch_bounds__(1024) void k_finish_emit_identity(
     uint32_t n_j, const uint32_t *__restrict__ jrank, const uint32_t *__restrict__ jstart, const uint32_t *__restrict__ jend,
     const uint32_t *__restrict__ amin, const uint32_t *__restrict__ amax, const unsigned long long *__restrict__ counts,
     const unsigned long long *__restrict__ creator, const uint32_t *__restrict__ jfirstbin, const uint32_t *__restrict__ tid_of_rank,
     const uint32_t *n_valid_total, const uint32_t *n_bins_total, TableDev out, uint4 *__restrict__ rank_items,
     uint32_t *__restrict__ rank_bits, uint32_t *__restrict__ jvalid, uint8_t *__restrict__ jstrand) {
-    __shared__ uint32_t bits_s[4][5];
+    __shared__ uint32_t bits_s[16][5];
     if (blockIdx.x == 0 && threadIdx.x == 0) out.hist_begin[*n_valid_total] = *n_bins_total;
     constexpr uint32_t ord_bits = 20;
     uint32_t o0 = 0, o1 = 0, a0 = ~0u, a1 = ~0u, oo = 0;
@@ -665,17 +663,13 @@ __global__ __launch_bounds__(256) void k_finish_emit_identity(
     if ((threadIdx.x & 63u) == 0) { bits_s[wave][0] = o0; bits_s[wave][1] = o1; bits_s[wave][2] = a0; bits_s[wave][3] = a1; bits_s[wave][4] = oo; }
     __syncthreads();
     if (threadIdx.x < 5) {
-        const uint32_t k = threadIdx.x;
-        if (k < 2) {
-            const uint32_t v = bits_s[0][k] | bits_s[1][k] | bits_s[2][k] | bits_s[3][k];
-            if (v) atomicOr(&rank_bits[1 + k], v);
-        } else if (k < 4) {
-            const uint32_t v = bits_s[0][k] & bits_s[1][k] & bits_s[2][k] & bits_s[3][k];
-            if (v != ~0u) atomicAnd(&rank_bits[1 + k], v);
-        } else {
-            const uint32_t v = bits_s[0][4] | bits_s[1][4] | bits_s[2][4] | bits_s[3][4];
-            if (v) atomicOr(&rank_bits[0], v);
-        }
+        const uint32_t k = threadIdx.x, nw = blockDim.x >> 6;
+        const bool is_and = k == 2 || k == 3;
+        uint32_t v = is_and ? ~0u : 0u;
+        for (uint32_t w = 0; w < nw; ++w) v = is_and ? (v & bits_s[w][k]) : (v | bits_s[w][k]);
+        if (k < 2) { if (v) atomicOr(&rank_bits[1 + k], v); }
+        else if (k < 4) { if (v != ~0u) atomicAnd(&rank_bits[1 + k], v); }
+        else if (v) atomicOr(&rank_bits[0], v);
     }
 }
 
@@ -825,13 +819,18 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                 rb.out_anchor_end, rb.out_strand, rb.out_motif, rb.out_read_counts,
                 rb.out_creator_order, rb.out_hist_begin, rb.out_ijunc};
     if (identity) {
-        hipLaunchKernelGGL(k_finish_emit_identity, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.jrank,
+        // blocks of 1024 threads, four junctions a thread and turn; at most 256 blocks: each ends in five atomics on one line
+        // (128 blocks of 256 threads took 150 us for the 3.9 M junctions of config 5's share: 119 junctions a thread, in turn)
+        hipLaunchKernelGGL(k_finish_emit_identity, dim3(std::min<uint32_t>((uint32_t)((J + 4095u) / 4096u) + (J ? 0u : 1u), 256u)), dim3(1024), 0, s, J, rb.jrank,
                            rb.jstart, rb.jend, rb.amin, rb.amax, rb.counts, rb.creator, rb.jfirstbin, tid_of_rank, rb.totals + 0,
                            rb.totals + 1, td, rb.rank_a, rb.totals + 2, rb.jvalid, rb.jstrand);
         ipx_prof_mark(s, IPXK_EMIT_J);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_finish_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.first, rb.creator,
+    // (blocks of 1024 threads, a grid that grows with J up to 256 blocks -- every block ends in atomics on one line; 128 blocks
+    // of 256 threads left a thread a hundred junctions, one after the other, in a table of millions)
+    const dim3 j_grid(std::min<uint32_t>((uint32_t)((J + 4095u) / 4096u) + (J ? 0u : 1u), 256u));
+    hipLaunchKernelGGL(k_finish_junctions, j_grid, dim3(1024), 0, s, J, rb.first, rb.creator,
                        rb.jmotif, rb.jvalid, rb.jstrand, counters, rb.totals + 2);
     ipx_prof_mark(s, IPXK_FINISH_J);
     if (!identity) {
@@ -846,7 +845,7 @@ hipError_t ipx_launch_reduce(hipStream_t s, const SortedItems &si, const uint4 *
                            rb.bin_pos, rb.out_hist_value, rb.out_hist_count, identity);
         ipx_prof_mark(s, IPXK_EMIT_BINS);
     }
-    hipLaunchKernelGGL(k_emit_junctions, dim3(J < 256u * 128u ? (J + 255u) / 256u + (J ? 0u : 1u) : 128u), dim3(256), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
+    hipLaunchKernelGGL(k_emit_junctions, j_grid, dim3(1024), 0, s, J, rb.jvalid, rb.jpos, rb.jrank,
                        rb.jstart, rb.jend, rb.amin, rb.amax, rb.jstrand, rb.jmotif, rb.counts, rb.creator,
                        rb.jfirstbin, rb.bin_pos, tid_of_rank, rb.totals + 0, rb.totals + 1, td, rb.rank_a, rb.totals + 2, identity);
     ipx_prof_mark(s, IPXK_EMIT_J);

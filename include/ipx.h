@@ -303,7 +303,7 @@ int ipx_host_free(void *p);
  * throws at that alignment and its caller never sees a table; *out is then
  * filled from the records of all other alignments and has no reference
  * counterpart.
- * Which sort: LSD radix passes, or -- from 16 M records on -- a bucket sort whose leaves are sorted in LDS.  The leaf
+ * Which sort: LSD radix passes, or -- from 8 M records on -- a bucket sort whose leaves are sorted in LDS.  The leaf
  * sort takes an item's rank among the equal digits of its wave from the value an LDS returning atomic hands back, i.e.
  * it rests on lanes of one instruction that hit the same LDS word being served in lane order: measured (1.3 x 10^10
  * lane-operations without an exception, profiles/microbench/lds_atomic_order.hip), checked again at start-up in every

@@ -1015,16 +1015,17 @@ static int finalize_core(ipx_handle *h, int32_t memory, bool resort, int32_t sj_
         uint32_t *tot = h->d_small.as<uint32_t>();      // [0] junctions, [1] bins, [2] the bucket sort's overflow flag
         // Which sort: the bucket sort (ipx_bsort.hip: every record moves through HBM three times whatever the key
         // width) from IPX_BSORT_MIN records on, the LSD radix sort below that, for keys without 16 spare bits, and
-        // when a leaf of the bucket sort did not fit LDS.  Default 16 M records: measured on one MI355X the two are
-        // level at 2 M records (S: 0.720 / 0.718 ms per step, fourteen launches against twenty-four), the radix
-        // passes are ahead at 10 M records in random order (S shuffled: sort 0.66 / 0.71 ms: the leaf search of
-        // k_bs_assign is latency-bound on random keys) and the bucket sort wins where the passes are bandwidth-bound
-        // (L, 40 M records: 7.22 / 7.37 ms per step).  IPX_SORT=lsd: always LSD; tests force either.
+        // when a leaf of the bucket sort did not fit LDS.  Default 8 M records: measured on one MI355X the two are
+        // level at 2 M records (S: 0.720 / 0.718 ms per step, fourteen launches against twenty-four), the bucket sort
+        // is ahead at 10 M records in random order (S shuffled, round 5: sort 0.67 against 0.75 ms, step 1.27 against
+        // 1.37 -- in round 3, before k_bs_assign ran four search chains a thread, it was 0.71 against 0.66 and the
+        // default 16 M) and where the passes are bandwidth-bound (L, 40 M records: 7.22 / 7.37 ms per step).
+        // IPX_SORT=lsd: always LSD; tests force either.
         const uint64_t bsort_min = [] {                   // read per call: tests switch between runs
             const char *m = getenv("IPX_SORT");
             if (m && m[0] == 'l') return ~0ull;
             const char *e = getenv("IPX_BSORT_MIN");
-            return e ? (uint64_t)atoll(e) : (16ull << 20);
+            return e ? (uint64_t)atoll(e) : (8ull << 20);
         }();
         bool by_buckets = resort && R >= bsort_min && ipx_bsort_applicable(R, h->key);
         if (by_buckets && h->bsort_skip) { --h->bsort_skip; by_buckets = false; }     // it overflowed recently on this handle

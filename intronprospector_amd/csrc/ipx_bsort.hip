@@ -772,9 +772,14 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
     const uint64_t leaf_avg = avg_e && atoll(avg_e) > 0 ? (uint64_t)atoll(avg_e) : BS_LEAF_AVG;
     const uint64_t k_target = std::min<uint64_t>(std::max<uint64_t>(1, ipx_div_up(n, leaf_avg)), BS_MAX_LEAVES);
     const uint32_t m2 = (uint32_t)std::min<uint64_t>(n, k_target * BS_OVERSAMPLE);
-    // coarse ranges: ~1800 second-level sample keys each (a range that draws 1.6 x its share still fits its list),
-    // and few enough leaves per range that an uneven range stays below 256
-    uint32_t k1 = (uint32_t)std::max<uint64_t>(ipx_div_up(m2, 1800), ipx_div_up(k_target, 170));
+    // coarse ranges: ~600 second-level sample keys each, i.e. ~37 leaves -- a range's table holds 255 splitters, a fenced
+    // key takes two of them, and what does not fit is DROPPED (the range's last leaf then takes the rest and overflows).
+    // With ~1800 keys a range (rounds 3-5) the ranges over the hot junctions of 10 M unfolded short reads -- 1 900 keys
+    // with 500 to 16 000 copies each, neighbours in key order -- needed 180-212 of the 255 in every sort and more than
+    // 255 in one sort of eight (a model of the sampling on S's keys; on the device: every few steps a fallback to the
+    // radix passes and fifteen sorts without the bucket sort).  At ~600 the same ranges need 55-90.  From 13 M records
+    // on there are 256 ranges either way (L, config 5's share: unchanged)
+    uint32_t k1 = (uint32_t)std::max<uint64_t>(ipx_div_up(m2, 600), ipx_div_up(k_target, 170));
     k1 = std::min<uint32_t>(std::max<uint32_t>(k1, 1u), 256u);
     const uint32_t m1 = std::min<uint32_t>(std::max<uint32_t>(16u * k1, 256u), BS_CAP);     // 16 first-level sample keys per coarse range
     hipLaunchKernelGGL(k_bs_sample1, dim3(1), dim3(BS_NT), 0, s, buf_a, n, sq, k1, m1, coarse, list_n, overflow);

@@ -1,5 +1,5 @@
 """GPU parity for the two sorts of ipx_finalize: the bucket sort (csrc/ipx_bsort.hip: sampled splitters, two radix
-passes on a 16-bit leaf id, every leaf sorted in LDS) takes tables from 16 M records on, the LSD radix sort
+passes on a 16-bit leaf id, every leaf sorted in LDS) takes tables from 8 M records on, the LSD radix sort
 (csrc/ipx_sort.hip) the rest and the bucket sort's overflow cases.  IPX_BSORT_MIN / IPX_SORT force either on any size.
 Every case compares the whole device table with the oracle's (std::map order, junctions.hh:77-100)."""
 import numpy as np

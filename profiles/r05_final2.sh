@@ -30,3 +30,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_Sshuf -- python 
 cp $(find $O/prof_Sshuf -name '*kernel_stats.csv' | head -1) $O/kernel_stats_S_shuffled.csv
 rm -rf $O/prof_? $O/prof_Sshuf
 ls -la $O
+# for the notebook: S's 2.3 M folded records by either sort, same box
+for k in 1 2; do
+  python bench.py --steps 20 --warmup 5 $B > $O/S_radix_$k.json 2>> $O/ab.err
+  IPX_BSORT_MIN=1000000 python bench.py --steps 20 --warmup 5 $B > $O/S_bucket_$k.json 2>> $O/ab.err
+done
+python - <<'P'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r05g/S_*_?.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['ms_per_step'],4))
+P

@@ -1,58 +1,103 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
-from intronprospector_amd import synth
-from tests.oracle_binding import Oracle
+"""A CPU model of the bucket sort's splitter selection (csrc/ipx_bsort.hip: k_bs_sample1 / k_bs_sample2 / k_bs_sort2) on
+the keys of shuffled S -- 9.87 M unfolded (junction, read offset) records of 10 M synthetic short reads, 2.09 M distinct,
+1 900 keys with 500 to 16 000 copies each.  Why: with IPX_BSORT_MIN=8000000 the device sorted that table by buckets in
+one run (1.27 ms a step) and fell back to the radix passes every few steps in the next (1.34 ms), and the library does
+not say which leaf overflowed.  The model does: the order of the records in memory varies from step to step (the scan's
+stripe reservations), the sample is taken at fixed positions, so every step draws another sample; with ~1800 sample keys
+per coarse range a range over the hot junctions needs 180-212 of its 255 splitter slots (a fenced key takes two), and
+in one sort of eight more than 255: the rest is dropped and the range's last leaf holds 18 000 records.  With ~600 keys
+a range the same ranges need 55-90.  What remains is a leaf of neighbouring keys with 500-1500 copies each that no fence
+caught plus sampling noise: 3 917 records at worst in 50 sorts (the leaf's capacity is 4 096).
 
-def load_keys():
-    b,names,_=synth.short_reads(10_000_000, seed=20251024)
-    o=Oracle(targets=names); o.process(b); tab=o.table(); o.close()
-    n=tab['n_offsets'].astype(np.int64); offs=tab['offsets'].astype(np.uint64)
-    j=np.repeat(np.arange(len(n),dtype=np.uint64), n)
-    return (j<<np.uint64(16))|offs
+usage (CPU only; needs oracle/libipxo.so):  python profiles/experiments/bsort_splitter_model.py [trials]
+Test infrastructure: the keys come from the oracle's table; nothing here is on the product's path."""
+import os
+import sys
 
-def splitters(keys, leaf_avg=1365, oversample=16, heavy_d=10, listcap=4096):
-    n=len(keys)
-    k_target=min(max(1,-(-n//leaf_avg)),43000)
-    m2=min(n,k_target*oversample)
-    k1=max(-(-m2//1800), -(-k_target//170)); k1=min(max(k1,1),256)
-    m1=min(max(16*k1,256),4096)
-    m=min(n,m1)
-    s1=np.sort(keys[(np.arange(m,dtype=np.int64)*n)//m])
-    coarse=s1[((np.arange(1,k1,dtype=np.int64))*m)//k1]
-    g=np.arange(m2,dtype=np.int64)
-    s2=keys[(g*n+n//2)//m2]
-    c=np.searchsorted(coarse,s2,side='right')
-    allsp=[]
-    dropped=0
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+BS_CAP, BS_LISTCAP, BS_OVERSAMPLE, BS_MAX_LEAVES = 4096, 4096, 16, 43000
+
+
+def shuffled_s_keys():
+    """(junction index << 16) | read offset of every record of S: the order of the device's squeezed keys, ties included"""
+    from intronprospector_amd import synth
+    from tests.oracle_binding import Oracle
+    b, names, _ = synth.short_reads(10_000_000, seed=20251024)
+    o = Oracle(targets=names)
+    o.process(b)
+    tab = o.table()
+    o.close()
+    n = tab["n_offsets"].astype(np.int64)
+    j = np.repeat(np.arange(len(n), dtype=np.uint64), n)
+    return (j << np.uint64(16)) | tab["offsets"].astype(np.uint64)
+
+
+def splitters(keys, per_range, leaf_avg=BS_CAP // 3, heavy_d=10):
+    """ipx_launch_bsort's plan and the three sampling kernels; per_range: second-level sample keys aimed at per coarse range"""
+    n = len(keys)
+    k_target = min(max(1, -(-n // leaf_avg)), BS_MAX_LEAVES)
+    m2 = min(n, k_target * BS_OVERSAMPLE)
+    k1 = min(max(max(-(-m2 // per_range), -(-k_target // 170)), 1), 256)
+    m = min(n, min(max(16 * k1, 256), BS_CAP))
+    s1 = np.sort(keys[(np.arange(m, dtype=np.int64) * n) // m])
+    coarse = s1[(np.arange(1, k1, dtype=np.int64) * m) // k1]
+    s2 = keys[(np.arange(m2, dtype=np.int64) * n + n // 2) // m2]
+    c = np.searchsorted(coarse, s2, side="right")
+    order = np.argsort(c, kind="stable")
+    cs, s2s = c[order], s2[order]
+    starts = np.searchsorted(cs, np.arange(k1 + 1))
+    bounds, dropped, most = [], 0, 0
     for r in range(k1):
-        lst=np.sort(s2[c==r])[:listcap]   # (order of arrival differs on the device when > listcap; ignore)
-        mm=len(lst)
-        f=(mm+oversample//2)//oversample; f=min(max(f,1),256)
-        out=[]
-        for t in range(f-1):
-            rr=((t+1)*mm)//f
-            v=lst[rr]
-            dup = t>=1 and v==lst[(t*mm)//f]
-            heavy = (rr+heavy_d<mm and lst[rr+heavy_d]==v) or (rr>=heavy_d and lst[rr-heavy_d]==v)
-            if dup: continue
+        lst = np.sort(s2s[starts[r]:starts[r + 1]])[:BS_LISTCAP]
+        mm = len(lst)
+        f = min(max((mm + BS_OVERSAMPLE // 2) // BS_OVERSAMPLE, 1), 256)
+        out = []
+        for t in range(f - 1):
+            rr = ((t + 1) * mm) // f
+            v = lst[rr]
+            if t >= 1 and v == lst[(t * mm) // f]:
+                continue
+            heavy = (rr + heavy_d < mm and lst[rr + heavy_d] == v) or (rr >= heavy_d and lst[rr - heavy_d] == v)
             out.append(v)
-            if heavy: out.append(v+np.uint64(1))
-        if len(out)>255: dropped+=len(out)-255; out=out[:255]
-        allsp.append((r,np.array(out,dtype=np.uint64)))
-    return coarse, allsp, dropped
+            if heavy:
+                out.append(v + np.uint64(1))
+        most = max(most, len(out))
+        if len(out) > 255:
+            dropped += len(out) - 255
+            out = out[:255]
+        if r > 0:
+            bounds.append(coarse[r - 1:r])
+        bounds.append(np.array(out, dtype=np.uint64))
+    return np.concatenate(bounds), k1, dropped, most
 
-def leaf_sizes(keys, coarse, allsp):
-    # leaf id = (coarse idx, fine idx) ; build global boundary list
-    bounds=[]
-    for r,sp in allsp:
-        if r>0: bounds.append(coarse[r-1:r])
-        bounds.append(sp)
-    bnd=np.concatenate(bounds)
-    # boundaries must be ascending (fine splitters lie inside their coarse range)
-    ids=np.searchsorted(bnd,keys,side='right')
-    cnt=np.bincount(ids,minlength=len(bnd)+1)
-    return ids,cnt
 
-if __name__=="__main__":
-    keys=load_keys()
-    np.save('/tmp/sim/keys.npy',keys)
+def worst_mixed_leaf(keys, bnd):
+    """size of the largest leaf whose keys are not all equal (a leaf of equal keys may have any size)"""
+    ids = np.searchsorted(bnd, keys, side="right")
+    cnt = np.bincount(ids, minlength=len(bnd) + 1)
+    worst = 0
+    for b in np.argsort(cnt)[::-1][:600]:
+        if cnt[b] <= worst:
+            break
+        kk = keys[ids == b]
+        if kk.min() != kk.max():
+            worst = int(cnt[b])
+            break
+    return worst, len(cnt)
+
+
+if __name__ == "__main__":
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    keys = shuffled_s_keys()
+    rng = np.random.default_rng(2)
+    for per_range in (1800, 600):
+        for t in range(trials):
+            k = keys[rng.permutation(len(keys))]
+            bnd, k1, dropped, most = splitters(k, per_range)
+            worst, leaves = worst_mixed_leaf(k, bnd)
+            print("keys a range %4d: %3d ranges, %5d leaves, most splitters in a range %3d, dropped %2d, largest mixed leaf %5d%s"
+                  % (per_range, k1, leaves, most, dropped, worst, "  <- does not fit LDS" if worst > BS_CAP else ""), flush=True)

@@ -73,6 +73,39 @@ def test_config_S_10M_short_reads():
     ora.close()
 
 
+def test_config_S_10M_short_reads_in_random_order(monkeypatch, capfd):
+    """The reference's --unsorted mode (junctions_extractor.cc:678-683) at BASELINE's size: the 10 M alignments of S in
+    random order.  Nothing folds, 9.87 M records reach the sort -- the bucket sort's by default (8 M records on) --, and
+    the 1 900 (junction, offset) keys with 500 to 16 000 copies each are fenced into leaves of their own; with fewer
+    coarse ranges their fences outgrew a range's splitter table in one sort of eight and the handle fell back to the
+    radix passes (profiles/experiments/bsort_splitter_model.py).  The whole table against the oracle's, five finalizes
+    (every one draws another sample: the records' order in memory differs from push to push), none of them a fallback."""
+    import intronprospector_amd as ipa
+    from intronprospector_amd import synth
+    monkeypatch.setenv("IPX_DEBUG_PLAN", "1")
+    batch, names, _ = synth.short_reads(10_000_000, seed=synth.SEED_S)
+    shuffled = synth.permute_batch(batch, np.random.default_rng(11).permutation(len(batch["tid"])))
+    del batch
+    ora = Oracle(targets=names)
+    ora.process(shuffled)
+    tab = ora.table()
+    ora.close()
+    ex = ipa.JunctionsExtractor(targets=names)
+    digests = set()
+    for _ in range(5):
+        ex.clear()
+        ex.push(shuffled, base_read_index=0)
+        t = ex.get_junctions()
+        digests.add(_digest(t))
+    ex.close()
+    _check_properties(t, 10_000_000)
+    assert int(t["n_records"]) > 9_000_000
+    helpers.compare_tables(t, tab)
+    assert len(digests) == 1
+    err = capfd.readouterr().err
+    assert "bucket sort overflowed" not in err, [l for l in err.splitlines() if "overflowed" in l]
+
+
 def test_config_L_long_reads():
     from intronprospector_amd import synth
     batch, names, _ = synth.long_reads(200_000, seed=synth.SEED_L)

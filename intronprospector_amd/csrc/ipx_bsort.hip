@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_bs_assign(uint4 *__restrict__ items, ui
     uint32_t off = 0;
     for (uint32_t w = 0; w < wave; ++w) off += ws[w];
     base[t] = off + incl - v;
-    if (blockIdx.x == 0 && t == 0) *n_leaves_out = ws[0] + ws[1] + ws[2] + ws[3];
+    if (blockIdx.x == 0 && t == 0) { n_leaves_out[0] = ws[0] + ws[1] + ws[2] + ws[3]; n_leaves_out[1] = 0; }   // [1]: k_bs_big_leaves' count
     __syncthreads();
     // Four records per thread at a time: a record's search is a chain of sixteen dependent look-ups (eight in the coarse
     // table in LDS, eight in its range's fine table in L2), and one chain per thread left the kernel waiting -- 0.47 ms
@@ -570,13 +570,41 @@ __global__ __launch_bounds__(256) void k_bs_bounds(const uint4 *__restrict__ ite
     }
 }
 
+// ---- 3a': the leaves of more than n_min records, listed (in any order) for the launch that sorts them.  That launch
+// used to walk ALL leaves, block b taking b, b + grid, ...: one leaf in twenty is large, so a block met none or three of
+// them and the kernel took as long as its unluckiest block -- 80 us for the 600 large leaves of 9.9 M unfolded short-read
+// records, 140 us for L's.  A leaf's bounds are read the way k_bs_leaf reads them.
+__global__ __launch_bounds__(256) void k_bs_big_leaves(const uint32_t *__restrict__ start, uint32_t *__restrict__ n_leaves_p,
+                                                       uint32_t n_min, uint32_t *__restrict__ list) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, n_leaves = n_leaves_p[0];
+    bool big = false;
+    if (b < n_leaves) {
+        const uint32_t s = start[b];
+        if (s != BS_SENT) {
+            uint32_t e = start[b + 1];
+            if (e == BS_SENT) {
+                uint32_t k = b + 2;
+                while ((e = start[k]) == BS_SENT) ++k;              // start[n_leaves] is always set
+            }
+            big = e - s > n_min;
+        }
+    }
+    const uint64_t m = ipx_ballot(big);                              // one atomic per wave
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n_leaves_p + 1, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (big) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = b;
+}
+
 // ---- 3b: every leaf sorted in LDS, written back without its id.  direct_n != 0: the whole array is one leaf.
 // Two launches share the leaves: IPT = 8 takes those of up to 2048 records (32 KiB of tile: four blocks per CU;
 // 19 of 20 leaves), IPT = 16 the larger ones (n > n_min) and what does not fit LDS at all.
 template <uint32_t IPT>
 __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, const uint32_t *__restrict__ start,
                                                    const uint32_t *__restrict__ n_leaves_p, uint32_t direct_n,
-                                                   uint32_t n_min, uint32_t max_bits, uint32_t *__restrict__ overflow) {
+                                                   uint32_t n_min, uint32_t max_bits, uint32_t *__restrict__ overflow,
+                                                   const uint32_t *__restrict__ list) {
     constexpr uint32_t CAP = BS_NT * IPT;
     __shared__ BsShared<IPT> sh;
 #ifdef IPX_BS_STATS
@@ -584,21 +612,31 @@ __global__ __launch_bounds__(BS_NT) void k_bs_leaf(uint4 *__restrict__ items, co
     uint32_t st_leaves = 0;
 #endif
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t n_leaves = direct_n ? 1u : *n_leaves_p;
-    // thread 0 fetches a leaf's bounds one leaf ahead: two dependent loads that would otherwise open every leaf
-    uint32_t nx_s = 0, nx_e = direct_n;
-    if (t == 0 && !direct_n && blockIdx.x < n_leaves) { nx_s = start[blockIdx.x]; nx_e = start[blockIdx.x + 1]; }
+    // list: this launch takes the leaves k_bs_big_leaves listed (n_leaves_p[1] of them) instead of all; uniform per launch
+    const uint32_t n_leaves = direct_n ? 1u : (list ? n_leaves_p[1] : n_leaves_p[0]);
+    // thread 0 fetches a leaf's bounds one leaf ahead: two dependent loads (three with a list) that would otherwise open
+    // every leaf
+    uint32_t nx_b = blockIdx.x, nx_s = 0, nx_e = direct_n;
+    if (t == 0 && !direct_n && blockIdx.x < n_leaves) {
+        if (list) nx_b = list[blockIdx.x];
+        nx_s = start[nx_b];
+        nx_e = start[nx_b + 1];
+    }
 #pragma unroll 1
-    for (uint32_t b = blockIdx.x; b < n_leaves; b += gridDim.x) {
+    for (uint32_t li = blockIdx.x; li < n_leaves; li += gridDim.x) {
         if (t == 0) {
             uint32_t s = nx_s, e = nx_e;
             if (!direct_n) {
                 if (s != BS_SENT && e == BS_SENT) {
-                    uint32_t k = b + 2;
+                    uint32_t k = nx_b + 2;
                     while ((e = start[k]) == BS_SENT) ++k;          // start[n_leaves] is always set
                 }
-                const uint32_t nb = b + gridDim.x;
-                if (nb < n_leaves) { nx_s = start[nb]; nx_e = start[nb + 1]; }
+                const uint32_t ni = li + gridDim.x;
+                if (ni < n_leaves) {
+                    nx_b = list ? list[ni] : ni;
+                    nx_s = start[nx_b];
+                    nx_e = start[nx_b + 1];
+                }
             }
             sh.rng[0] = s;
             sh.rng[1] = e;
@@ -735,8 +773,9 @@ bool ipx_bsort_applicable(uint64_t n, const KeyLayout &kl) {
 }
 
 size_t ipx_bsort_workspace_bytes(void) {
-    // coarse[256] u64 | list_n[256] | fine_n[256] | n_leaves (+ pad to 256 B) | fine[65536] u64 | start[65538] | lists[256 * LISTCAP] u64
-    return (size_t)256 * 8 + 256 * 4 + 256 * 4 + 256 + (size_t)65536 * 8 + (size_t)65540 * 4 + (size_t)256 * BS_LISTCAP * 8;
+    // coarse[256] u64 | list_n[256] | fine_n[256] | n_leaves, large leaves (+ pad to 256 B) | fine[65536] u64 | start[65538] |
+    // big_list[65536] | lists[256 * LISTCAP] u64
+    return (size_t)256 * 8 + 256 * 4 + 256 * 4 + 256 + (size_t)65536 * 8 + (size_t)65540 * 4 + (size_t)65540 * 4 + (size_t)256 * BS_LISTCAP * 8;
 }
 
 hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *dig_a, uint8_t *dig_b, uint64_t n,
@@ -750,6 +789,7 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
     uint32_t *n_leaves = (uint32_t *)w;          w += 256;
     uint64_t *fine = (uint64_t *)w;              w += (size_t)65536 * 8;
     uint32_t *start = (uint32_t *)w;             w += (size_t)65540 * 4;
+    uint32_t *big_list = (uint32_t *)w;          w += (size_t)65540 * 4;
     uint64_t *lists = (uint64_t *)w;
     static const uint32_t n_cus = [] {
         int dev = 0, cus = 0;
@@ -760,9 +800,9 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
         hipError_t e = hipMemsetAsync(overflow, 0, sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
         if (n <= BS_CAP / 2)
-            hipLaunchKernelGGL(k_bs_leaf<BS_IPT / 2>, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, 0u, kl.total_bits, overflow);
+            hipLaunchKernelGGL(k_bs_leaf<BS_IPT / 2>, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, 0u, kl.total_bits, overflow, nullptr);
         else
-            hipLaunchKernelGGL(k_bs_leaf<BS_IPT>, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, 0u, kl.total_bits, overflow);
+            hipLaunchKernelGGL(k_bs_leaf<BS_IPT>, dim3(1), dim3(BS_NT), 0, s, buf_a, start, n_leaves, (uint32_t)n, 0u, kl.total_bits, overflow, nullptr);
         ipx_prof_mark(s, IPXK_BS_LEAF);
         return hipGetLastError();
     }
@@ -801,9 +841,11 @@ hipError_t ipx_launch_bsort(hipStream_t s, uint4 *buf_a, uint4 *buf_b, uint8_t *
     hipLaunchKernelGGL(k_bs_bounds, dim3((uint32_t)ipx_div_up(ipx_div_up(n, 16), 256)), dim3(256), 0, s, buf_a, dig_a, n, n_leaves, start);
     ipx_prof_mark(s, IPXK_BS_BOUNDS);
     const uint32_t leaf_blocks = (uint32_t)std::min<uint64_t>(k_target + k1, (uint64_t)n_cus * 16);
-    hipLaunchKernelGGL(k_bs_leaf<BS_IPT / 2>, dim3(leaf_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, 0u, kl.total_bits, overflow);
+    // (n_leaves <= 65536: 256 ranges of <= 256 leaves)
+    hipLaunchKernelGGL(k_bs_big_leaves, dim3(256), dim3(256), 0, s, start, n_leaves, BS_CAP / 2, big_list);
+    hipLaunchKernelGGL(k_bs_leaf<BS_IPT / 2>, dim3(leaf_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, 0u, kl.total_bits, overflow, nullptr);
     const uint32_t big_blocks = (uint32_t)std::min<uint64_t>(k_target / 8 + 1, (uint64_t)n_cus * 2);
-    hipLaunchKernelGGL(k_bs_leaf<BS_IPT>, dim3(big_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, BS_CAP / 2, kl.total_bits, overflow);
+    hipLaunchKernelGGL(k_bs_leaf<BS_IPT>, dim3(big_blocks), dim3(BS_NT), 0, s, buf_a, start, n_leaves, 0u, BS_CAP / 2, kl.total_bits, overflow, big_list);
     ipx_prof_mark(s, IPXK_BS_LEAF);
     return hipGetLastError();
 }

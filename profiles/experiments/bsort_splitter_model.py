@@ -36,13 +36,14 @@ def shuffled_s_keys():
     return (j << np.uint64(16)) | tab["offsets"].astype(np.uint64)
 
 
-def splitters(keys, per_range, leaf_avg=BS_CAP // 3, heavy_d=10):
-    """ipx_launch_bsort's plan and the three sampling kernels; per_range: second-level sample keys aimed at per coarse range"""
+def splitters(keys, per_range, leaf_avg=BS_CAP // 3, heavy_d=10, first_per_range=16):
+    """ipx_launch_bsort's plan and the three sampling kernels; per_range: second-level sample keys aimed at per coarse range;
+    first_per_range: first-level sample keys per coarse range (16 in the library: k_bs_sample1 sorts 16 * k1 keys in one block)"""
     n = len(keys)
     k_target = min(max(1, -(-n // leaf_avg)), BS_MAX_LEAVES)
     m2 = min(n, k_target * BS_OVERSAMPLE)
     k1 = min(max(max(-(-m2 // per_range), -(-k_target // 170)), 1), 256)
-    m = min(n, min(max(16 * k1, 256), BS_CAP))
+    m = min(n, min(max(first_per_range * k1, 256), BS_CAP))
     s1 = np.sort(keys[(np.arange(m, dtype=np.int64) * n) // m])
     coarse = s1[(np.arange(1, k1, dtype=np.int64) * m) // k1]
     s2 = keys[(np.arange(m2, dtype=np.int64) * n + n // 2) // m2]
@@ -50,7 +51,7 @@ def splitters(keys, per_range, leaf_avg=BS_CAP // 3, heavy_d=10):
     order = np.argsort(c, kind="stable")
     cs, s2s = c[order], s2[order]
     starts = np.searchsorted(cs, np.arange(k1 + 1))
-    bounds, dropped, most = [], 0, 0
+    bounds, dropped, most, longest = [], 0, 0, int(np.diff(starts).max())
     for r in range(k1):
         lst = np.sort(s2s[starts[r]:starts[r + 1]])[:BS_LISTCAP]
         mm = len(lst)
@@ -72,7 +73,7 @@ def splitters(keys, per_range, leaf_avg=BS_CAP // 3, heavy_d=10):
         if r > 0:
             bounds.append(coarse[r - 1:r])
         bounds.append(np.array(out, dtype=np.uint64))
-    return np.concatenate(bounds), k1, dropped, most
+    return np.concatenate(bounds), k1, dropped, most, longest
 
 
 def worst_mixed_leaf(keys, bnd):
@@ -97,7 +98,12 @@ if __name__ == "__main__":
     for per_range in (1800, 600):
         for t in range(trials):
             k = keys[rng.permutation(len(keys))]
-            bnd, k1, dropped, most = splitters(k, per_range)
+            bnd, k1, dropped, most, longest = splitters(k, per_range)
             worst, leaves = worst_mixed_leaf(k, bnd)
-            print("keys a range %4d: %3d ranges, %5d leaves, most splitters in a range %3d, dropped %2d, largest mixed leaf %5d%s"
-                  % (per_range, k1, leaves, most, dropped, worst, "  <- does not fit LDS" if worst > BS_CAP else ""), flush=True)
+            print("keys a range %4d: %3d ranges, %5d leaves, longest second-level list %4d, most splitters in a range %3d, dropped %2d, "
+                  "largest mixed leaf %5d%s" % (per_range, k1, leaves, longest, most, dropped, worst,
+                                                "  <- does not fit LDS" if worst > BS_CAP else ""), flush=True)
+    # k_bs_sample1 with half the first-level keys: how uneven do the coarse ranges get (the list holds BS_LISTCAP keys)
+    for first in (16, 8):
+        longest = [splitters(keys[rng.permutation(len(keys))], 600, first_per_range=first)[4] for _ in range(trials)]
+        print("first-level keys a range %2d: longest second-level list %s of %d" % (first, longest, BS_LISTCAP), flush=True)
